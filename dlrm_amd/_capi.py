@@ -1,0 +1,81 @@
+"""ctypes binding of libdlrm_amd.so -- the C ABI declared in include/dlrm_amd.h.
+
+There is no CPU fallback: if the library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdlrm_amd.so")
+
+OK = 0
+F32, BF16 = 0, 1
+I32, I64 = 0, 1
+POOL_SUM, POOL_MEAN = 0, 1
+DUP_ACCUMULATE, DUP_LAST_WINS = 0, 1
+OPT_SGD, OPT_ADAGRAD_ROWWISE = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class DlrmError(RuntimeError):
+    pass
+
+
+class EmbBagDesc(C.Structure):
+    _fields_ = [
+        ("d_weight", C.c_void_p),
+        ("d_table_row_offsets", C.c_void_p),
+        ("total_rows", C.c_int64),
+        ("num_tables", C.c_int32),
+        ("dim", C.c_int32),
+        ("row_dtype", C.c_int32),
+        ("idx_dtype", C.c_int32),
+        ("d_indices", C.c_void_p),
+        ("d_offsets", C.c_void_p),
+        ("n_indices", C.c_int64),
+        ("batch", C.c_int64),
+        ("include_last_offset", C.c_int32),
+        ("pooling", C.c_int32),
+        ("d_error_flag", C.c_void_p),
+    ]
+
+
+class SparseOpt(C.Structure):
+    _fields_ = [
+        ("optimizer", C.c_int32),
+        ("dup_mode", C.c_int32),
+        ("lr", C.c_float),
+        ("eps", C.c_float),
+        ("d_opt_state", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libdlrm_amd.so (built in-tree by `make -C dlrm_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DlrmError(
+                "libdlrm_amd.so not found at %s: build it with `make -C dlrm_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dlrm_last_error.restype = C.c_char_p
+        _lib.dlrm_target_arch.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise DlrmError("dlrm_amd error %d: %s" % (rc, lib().dlrm_last_error().decode()))
+
+
+def declared_symbols():
+    """Every function include/dlrm_amd.h declares (parsed from the header)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "dlrm_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlrm_[a-z0-9_]+)\s*\(", hdr)))

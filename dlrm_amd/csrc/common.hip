@@ -1,0 +1,58 @@
+// Error reporting, version query and table initialisation.
+#include "common.h"
+
+#include <stdarg.h>
+
+namespace dlrm {
+
+char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+template <typename T>
+__global__ void table_init_uniform_kernel(T *dst, int64_t n, uint64_t seed, int64_t first) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = (float)(splitmix64(seed + (uint64_t)(first + i)) >> 40) * (1.0f / 16777216.0f);
+        if constexpr (sizeof(T) == 4)
+            dst[i] = v;
+        else
+            dst[i] = (T)f32_to_bf16_bits(v);
+    }
+}
+
+}  // namespace dlrm
+
+using namespace dlrm;
+
+extern "C" const char *dlrm_last_error(void) { return err_buf(); }
+extern "C" int dlrm_version(void) { return 1000; }
+extern "C" const char *dlrm_target_arch(void) { return "gfx950"; }
+
+extern "C" int dlrm_table_init_uniform(void *dst, int row_dtype, int64_t n, uint64_t seed, int64_t first,
+                                       dlrm_stream_t stream) {
+    DLRM_REQUIRE(n >= 0, "n < 0");
+    DLRM_REQUIRE(row_dtype == DLRM_F32 || row_dtype == DLRM_BF16, "row_dtype %d", row_dtype);
+    if (n == 0) return DLRM_OK;
+    DLRM_REQUIRE(dst != nullptr, "dst is NULL");
+    const int threads = 256;
+    const int64_t want = ceil_div(n, threads);
+    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+    if (row_dtype == DLRM_F32)
+        hipLaunchKernelGGL(table_init_uniform_kernel<float>, dim3(blocks), dim3(threads), 0, as_stream(stream),
+                           static_cast<float *>(dst), n, seed, first);
+    else
+        hipLaunchKernelGGL(table_init_uniform_kernel<uint16_t>, dim3(blocks), dim3(threads), 0,
+                           as_stream(stream), static_cast<uint16_t *>(dst), n, seed, first);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}

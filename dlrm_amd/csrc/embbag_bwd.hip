@@ -1,0 +1,381 @@
+// EmbeddingBag sparse backward fused with the row-wise optimizer step (gfx950).
+//
+//  1. expand : every occurrence p of a row in the batch becomes a pair
+//              (key = global row, value = bag).
+//  2. sort   : stable LSD radix sort of the pairs by key (rocPRIM device
+//              primitive, only as many key bits as total_rows needs).  Stability
+//              keeps the occurrences of one row in position order, so the
+//              reduction order -- and the result -- is reproducible.
+//  3. update : one G-lane group per sorted position; the group that sits on
+//              the first occurrence of a row (its "leader") sums the pooled
+//              gradients of all occurrences of that row, applies SGD or
+//              row-wise Adagrad and writes the row back.  Every touched row is
+//              read once and written once; other groups exit after two key
+//              loads.
+//
+// HBM-bound: algorithmic bytes per call = n_idx*dim*4 (gradient rows) +
+// 2*U*dim*row_bytes (read-modify-write of U unique rows) + n_idx*idx_bytes.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace dlrm {
+
+int validate_embbag(const dlrm_embbag *e);
+
+constexpr int kBwdThreads = 256;
+
+template <typename KEY>
+struct WsLayout {
+    KEY *keys_in, *keys_out;
+    int32_t *vals_in, *vals_out;
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
+    size_t total;
+};
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+static inline int key_bits(int64_t total_rows) {
+    int b = 1;
+    while ((total_rows >> b) != 0) b++;
+    return b;
+}
+
+template <typename KEY>
+static int ws_layout(int64_t n, int bits, void *base, WsLayout<KEY> *L) {
+    size_t tmp = 0;
+    hipError_t err = rocprim::radix_sort_pairs(nullptr, tmp, (KEY *)nullptr, (KEY *)nullptr, (int32_t *)nullptr,
+                                               (int32_t *)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t)0,
+                                               false);
+    if (err != hipSuccess) return set_error(DLRM_ERR_HIP, "radix_sort_pairs size query: %s", hipGetErrorString(err));
+    char *p = static_cast<char *>(base);
+    size_t o = 0;
+    L->keys_in = reinterpret_cast<KEY *>(p + o); o += align_up(sizeof(KEY) * (size_t)n);
+    L->keys_out = reinterpret_cast<KEY *>(p + o); o += align_up(sizeof(KEY) * (size_t)n);
+    L->vals_in = reinterpret_cast<int32_t *>(p + o); o += align_up(sizeof(int32_t) * (size_t)n);
+    L->vals_out = reinterpret_cast<int32_t *>(p + o); o += align_up(sizeof(int32_t) * (size_t)n);
+    L->sort_tmp = p + o; o += align_up(tmp);
+    L->sort_tmp_bytes = tmp;
+    L->total = o;
+    return DLRM_OK;
+}
+
+struct BwdParams {
+    void *w;
+    const int64_t *tro;
+    int64_t total_rows;
+    int T;
+    int D;
+    const void *idx;
+    const void *off;
+    int64_t n_idx;
+    int64_t B;
+    int64_t n_bags;
+    int include_last;
+    int mean;
+    const float *grad;
+    int64_t grad_ld;
+    int *err;
+    int last_wins;
+    int adagrad;
+    float lr;
+    float eps;
+    float *state;
+};
+
+// lanes_per_bag lanes walk the positions of one bag
+template <typename IDX, typename KEY>
+__global__ __launch_bounds__(kBwdThreads) void expand_pairs_kernel(BwdParams p, int lanes_per_bag, KEY *keys,
+                                                                    int32_t *vals) {
+    const int64_t tid = (int64_t)blockIdx.x * kBwdThreads + threadIdx.x;
+    const int64_t g = tid / lanes_per_bag;
+    const int lane = (int)(tid % lanes_per_bag);
+    if (g >= p.n_bags) return;
+    const IDX *off = static_cast<const IDX *>(p.off);
+    const IDX *idx = static_cast<const IDX *>(p.idx);
+    const int64_t start = (int64_t)off[g];
+    const int64_t end = (g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
+    const int t = (int)((uint32_t)g / (uint32_t)p.B);
+    const int64_t tbase = p.tro ? p.tro[t] : 0;
+    const int64_t trows = p.tro ? p.tro[t + 1] - tbase : p.total_rows;
+    bool bad = false;
+    for (int64_t q = start + lane; q < end; q += lanes_per_bag) {
+        const int64_t r = (int64_t)idx[q];
+        KEY k;
+        if (r < 0 || r >= trows) {
+            k = (KEY)p.total_rows;  // sorts behind every real row and is skipped by the update
+            bad = true;
+        } else {
+            k = (KEY)(tbase + r);
+        }
+        keys[q] = k;
+        vals[q] = (int32_t)g;
+    }
+    if (bad && p.err) *p.err = 1;
+}
+
+template <typename ROW, int VEC16>
+struct RowRW;
+
+template <>
+struct RowRW<float, 1> {
+    static constexpr int NF = 4;
+    __device__ static void load(const void *w, int64_t e, float (&v)[4]) {
+        const float4 x = *reinterpret_cast<const float4 *>(static_cast<const float *>(w) + e);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    }
+    __device__ static void store(void *w, int64_t e, const float (&v)[4]) {
+        *reinterpret_cast<float4 *>(static_cast<float *>(w) + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct RowRW<uint16_t, 1> {
+    static constexpr int NF = 8;
+    __device__ static void load(const void *w, int64_t e, float (&v)[8]) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(w) + e);
+        v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
+        v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
+        v[4] = __uint_as_float(x.z << 16); v[5] = __uint_as_float(x.z & 0xffff0000u);
+        v[6] = __uint_as_float(x.w << 16); v[7] = __uint_as_float(x.w & 0xffff0000u);
+    }
+    __device__ static void store(void *w, int64_t e, const float (&v)[8]) {
+        uint4 x;
+        x.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+        x.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+        x.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+        x.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+        *reinterpret_cast<uint4 *>(static_cast<uint16_t *>(w) + e) = x;
+    }
+};
+template <>
+struct RowRW<float, 0> {
+    static constexpr int NF = 1;
+    __device__ static void load(const void *w, int64_t e, float (&v)[1]) { v[0] = static_cast<const float *>(w)[e]; }
+    __device__ static void store(void *w, int64_t e, const float (&v)[1]) { static_cast<float *>(w)[e] = v[0]; }
+};
+template <>
+struct RowRW<uint16_t, 0> {
+    static constexpr int NF = 1;
+    __device__ static void load(const void *w, int64_t e, float (&v)[1]) {
+        v[0] = __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t *>(w)[e]) << 16);
+    }
+    __device__ static void store(void *w, int64_t e, const float (&v)[1]) {
+        static_cast<uint16_t *>(w)[e] = (uint16_t)f32_to_bf16_bits(v[0]);
+    }
+};
+
+// gradient vector of NF floats (grad rows are float32; 16-byte loads when VEC16)
+template <int NF>
+__device__ inline void load_grad(const float *g, float (&v)[NF]) {
+    if constexpr (NF == 1) {
+        v[0] = g[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NF; q += 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(g + q);
+            v[q] = x.x; v[q + 1] = x.y; v[q + 2] = x.z; v[q + 3] = x.w;
+        }
+    }
+}
+
+template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
+__global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
+                                                                     const int32_t *__restrict__ vals) {
+    using RW = RowRW<ROW, VEC16>;
+    constexpr int NF = RW::NF;
+    constexpr int GROUPS = kBwdThreads / G;
+    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
+    const int64_t i = (int64_t)blockIdx.x * GROUPS + grp;
+    if (i >= p.n_idx) return;
+    const KEY k = keys[i];
+    if ((int64_t)k >= p.total_rows) return;      // out-of-range index, reported by the expand kernel
+    if (i > 0 && keys[i - 1] == k) return;       // not the first occurrence of this row
+    const IDX *off = static_cast<const IDX *>(p.off);
+
+    int col[NC];
+    bool col_ok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        col[c] = (c * G + lig) * NF;
+        col_ok[c] = col[c] < p.D;
+    }
+    float acc[NC][NF];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
+
+    // the row itself can be fetched while the gradients are being summed
+    float w[NC][NF];
+    const int64_t e0 = (int64_t)k * p.D;
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (col_ok[c]) RW::load(p.w, e0 + col[c], w[c]);
+
+    int64_t j = i;
+    if (p.last_wins)
+        while (j + 1 < p.n_idx && keys[j + 1] == k) j++;
+    for (;;) {
+        const uint32_t g = (uint32_t)vals[j];
+        const uint32_t t = g / (uint32_t)p.B;
+        const uint32_t b = g - t * (uint32_t)p.B;
+        float sc = 1.0f;
+        if (p.mean) {
+            const int64_t s = (int64_t)off[g];
+            const int64_t e = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
+            sc = 1.0f / (float)(e - s);
+        }
+        const float *gp = p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) {
+                float v[NF];
+                load_grad<NF>(gp + col[c], v);
+#pragma unroll
+                for (int q = 0; q < NF; q++) acc[c][q] += v[q] * sc;
+            }
+        j++;
+        if (j >= p.n_idx || keys[j] != k) break;
+    }
+
+    float mult = p.lr;
+    if (p.adagrad) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) {
+#pragma unroll
+                for (int q = 0; q < NF; q++) ss += acc[c][q] * acc[c][q];
+            }
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) ss += __shfl_xor(ss, m, kWave);
+        const float st = p.state[k] + ss / (float)p.D;
+        if (lig == 0) p.state[k] = st;
+        mult = p.lr / (sqrtf(st) + p.eps);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (col_ok[c]) {
+#pragma unroll
+            for (int q = 0; q < NF; q++) w[c][q] -= mult * acc[c][q];
+            RW::store(p.w, e0 + col[c], w[c]);
+        }
+}
+
+template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
+static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, hipStream_t s) {
+    const int64_t blocks = ceil_div(p.n_idx, kBwdThreads / G);
+    hipLaunchKernelGGL((sparse_update_kernel<IDX, KEY, ROW, VEC16, G, NC>), dim3((unsigned)blocks),
+                       dim3(kBwdThreads), 0, s, p, keys, vals);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+template <typename IDX, typename KEY, typename ROW>
+static int dispatch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, bool vec16, int lanes,
+                           hipStream_t s) {
+    if (!vec16) {
+        if (lanes <= 64) return launch_update<IDX, KEY, ROW, 0, 64, 1>(p, keys, vals, s);
+        if (lanes <= 128) return launch_update<IDX, KEY, ROW, 0, 64, 2>(p, keys, vals, s);
+        return launch_update<IDX, KEY, ROW, 0, 64, 4>(p, keys, vals, s);
+    }
+    if (lanes <= 4) return launch_update<IDX, KEY, ROW, 1, 4, 1>(p, keys, vals, s);
+    if (lanes <= 8) return launch_update<IDX, KEY, ROW, 1, 8, 1>(p, keys, vals, s);
+    if (lanes <= 16) return launch_update<IDX, KEY, ROW, 1, 16, 1>(p, keys, vals, s);
+    if (lanes <= 32) return launch_update<IDX, KEY, ROW, 1, 32, 1>(p, keys, vals, s);
+    if (lanes <= 64) return launch_update<IDX, KEY, ROW, 1, 64, 1>(p, keys, vals, s);
+    if (lanes <= 128) return launch_update<IDX, KEY, ROW, 1, 64, 2>(p, keys, vals, s);
+    return launch_update<IDX, KEY, ROW, 1, 64, 4>(p, keys, vals, s);
+}
+
+template <typename IDX, typename KEY>
+static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_bytes, bool vec16, int lanes,
+                        hipStream_t s) {
+    WsLayout<KEY> L;
+    const int bits = key_bits(e->total_rows);
+    if (int rc = ws_layout<KEY>(e->n_indices, bits, ws, &L)) return rc;
+    DLRM_REQUIRE(ws_bytes >= L.total, "workspace too small: %zu < %zu bytes", ws_bytes, L.total);
+
+    const double avg_len = (double)e->n_indices / (double)p.n_bags;
+    int lpb = 1;
+    while (lpb < 64 && lpb * 2 <= avg_len) lpb <<= 1;
+    const int64_t blocks = ceil_div(p.n_bags * lpb, kBwdThreads);
+    hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks), dim3(kBwdThreads), 0, s, p, lpb,
+                       L.keys_in, L.vals_in);
+    DLRM_LAUNCH_CHECK();
+    size_t tmp = L.sort_tmp_bytes;
+    DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
+                                       (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
+    if (e->row_dtype == DLRM_BF16)
+        return dispatch_update<IDX, KEY, uint16_t>(p, L.keys_out, L.vals_out, vec16, lanes, s);
+    return dispatch_update<IDX, KEY, float>(p, L.keys_out, L.vals_out, vec16, lanes, s);
+}
+
+}  // namespace dlrm
+
+using namespace dlrm;
+
+extern "C" int dlrm_embbag_backward_workspace_bytes(const dlrm_embbag *e, size_t *bytes) {
+    if (int rc = validate_embbag(e)) return rc;
+    DLRM_REQUIRE(bytes != nullptr, "bytes is NULL");
+    const int bits = key_bits(e->total_rows);
+    const int64_t n = e->n_indices > 0 ? e->n_indices : 1;
+    if (bits <= 32) {
+        WsLayout<uint32_t> L;
+        if (int rc = ws_layout<uint32_t>(n, bits, nullptr, &L)) return rc;
+        *bytes = L.total;
+    } else {
+        WsLayout<uint64_t> L;
+        if (int rc = ws_layout<uint64_t>(n, bits, nullptr, &L)) return rc;
+        *bytes = L.total;
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld,
+                                           const dlrm_sparse_opt *opt, void *d_workspace, size_t workspace_bytes,
+                                           dlrm_stream_t stream) {
+    if (int rc = validate_embbag(e)) return rc;
+    DLRM_REQUIRE(opt != nullptr, "opt is NULL");
+    DLRM_REQUIRE(opt->optimizer == DLRM_OPT_SGD || opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE, "optimizer %d",
+                 opt->optimizer);
+    DLRM_REQUIRE(opt->dup_mode == DLRM_DUP_ACCUMULATE || opt->dup_mode == DLRM_DUP_LAST_WINS, "dup_mode %d",
+                 opt->dup_mode);
+    DLRM_REQUIRE(opt->optimizer != DLRM_OPT_ADAGRAD_ROWWISE || opt->d_opt_state != nullptr,
+                 "row-wise Adagrad needs d_opt_state");
+    const int64_t n_bags = (int64_t)e->num_tables * e->batch;
+    if (n_bags == 0 || e->n_indices == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_grad != nullptr && d_workspace != nullptr, "d_grad / d_workspace is NULL");
+    DLRM_REQUIRE(grad_ld >= (int64_t)e->num_tables * e->dim, "grad_ld too small");
+    DLRM_REQUIRE(n_bags < (1ll << 31) && e->n_indices < (1ll << 40), "batch too large for 32-bit bag ids");
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_workspace) % 256 == 0, "workspace must be 256-byte aligned");
+
+    BwdParams p;
+    p.w = e->d_weight; p.tro = e->d_table_row_offsets; p.total_rows = e->total_rows;
+    p.T = e->num_tables; p.D = e->dim; p.idx = e->d_indices; p.off = e->d_offsets;
+    p.n_idx = e->n_indices; p.B = e->batch; p.n_bags = n_bags;
+    p.include_last = e->include_last_offset; p.mean = e->pooling == DLRM_POOL_MEAN;
+    p.grad = d_grad; p.grad_ld = grad_ld; p.err = e->d_error_flag;
+    p.last_wins = opt->dup_mode == DLRM_DUP_LAST_WINS;
+    p.adagrad = opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE;
+    p.lr = opt->lr; p.eps = opt->eps; p.state = opt->d_opt_state;
+
+    const int esz = e->row_dtype == DLRM_F32 ? 4 : 2;
+    const int nf = 16 / esz;
+    const bool vec16 = (e->dim % nf == 0) && (reinterpret_cast<uintptr_t>(e->d_weight) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(d_grad) % 16 == 0) && (grad_ld % 4 == 0) && (e->dim % 4 == 0);
+    const int lanes = vec16 ? e->dim / nf : e->dim;
+    DLRM_REQUIRE(lanes <= 256, "dim=%d is too wide for this kernel", e->dim);
+
+    hipStream_t s = as_stream(stream);
+    const bool k64 = key_bits(e->total_rows) > 32;
+    const bool i64 = e->idx_dtype == DLRM_I64;
+    if (k64) {
+        if (i64) return run_backward<int64_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
+        return run_backward<int32_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
+    }
+    if (i64) return run_backward<int64_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
+    return run_backward<int32_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
+}

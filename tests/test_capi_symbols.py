@@ -1,0 +1,31 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and
+exports every symbol the header declares; bad arguments are rejected with a
+message instead of reaching a kernel."""
+import ctypes as C
+
+import pytest
+
+from dlrm_amd import _capi
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.lib()
+    names = _capi.declared_symbols()
+    assert len(names) >= 5
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.dlrm_target_arch() == b"gfx950"
+    assert L.dlrm_version() >= 1000
+
+
+def test_invalid_descriptor_is_rejected_without_launch():
+    L = _capi.lib()
+    d = _capi.EmbBagDesc()
+    d.num_tables, d.dim, d.batch = 2, 16, 4  # two tables but no row offsets
+    d.row_dtype, d.idx_dtype = _capi.F32, _capi.I64
+    rc = L.dlrm_embbag_forward(C.byref(d), None, C.c_int64(32), None)
+    assert rc == 1
+    assert b"d_table_row_offsets" in L.dlrm_last_error()
+    with pytest.raises(_capi.DlrmError):
+        _capi.check(rc)
+    assert L.dlrm_embbag_forward(None, None, C.c_int64(0), None) == 1
