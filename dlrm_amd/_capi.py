@@ -50,6 +50,30 @@ class SparseOpt(C.Structure):
     ]
 
 
+class LinearDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("d_x", C.c_void_p), ("x_ld", C.c_int64),
+        ("d_w", C.c_void_p), ("w_ld", C.c_int64),
+        ("d_bias", C.c_void_p),
+        ("d_y", C.c_void_p), ("y_ld", C.c_int64),
+        ("act", C.c_int32),
+    ]
+
+
+class LinearBwdDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("d_dz", C.c_void_p), ("dz_ld", C.c_int64),
+        ("d_w", C.c_void_p), ("w_ld", C.c_int64),
+        ("d_x", C.c_void_p), ("x_ld", C.c_int64),
+        ("d_dx", C.c_void_p), ("dx_ld", C.c_int64),
+        ("d_relu_mask", C.c_void_p), ("relu_mask_ld", C.c_int64),
+        ("d_dw", C.c_void_p), ("dw_ld", C.c_int64),
+        ("d_db", C.c_void_p),
+    ]
+
+
 _lib = None
 
 

@@ -1,0 +1,361 @@
+// float32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in,
+// f32 accumulate, bit-for-bit a k-ordered fmaf chain) with fused epilogues, for
+// the bottom/top MLP: forward (x W^T + b, ReLU), backward-data
+// (dz W, masked by the previous layer's ReLU) and backward-weight (dz^T x,
+// split over the batch dimension).
+//
+// One kernel template covers the three products.  C[i][j] = sum_r A(i,r) B(j,r)
+// where each operand is addressed either with the reduction index contiguous
+// ("RC": element (i,r) at base + i*ld + r) or with the output index contiguous
+// ("RS": element (i,r) at base + r*ld + i):
+//     forward        : A = x  (RC), B = W (RC)       C = y  [M,N]
+//     backward data  : A = dz (RC), B = W (RS)       C = dx [M,K]
+//     backward weight: A = dz (RS), B = x (RS)       C = dW [N,K]   (reduction over M)
+//
+// Tiling: 128x128 output tile per 256-thread workgroup, 32-deep reduction
+// steps, 2x2 waves each owning 64x64 (2x2 MFMA tiles of 32x32, 64 accumulator
+// registers).  Global -> registers -> LDS with the next step's loads issued
+// before the current step's MFMAs (double-buffered LDS, one barrier per step).
+// LDS images: RC operands [128][32+4] (144-byte rows: conflict-free
+// ds_read_b128 fragments, each lane gets 4 consecutive r; lanes 32..63 take the
+// next 4), RS operands [32][128] (ds_read_b32 fragments).  MFMA j of a group
+// of four consumes r = 8q+j on lanes 0..31 and r = 8q+4+j on lanes 32..63 for
+// both operands, so the pairing of reduction indices is consistent.
+#include "common.h"
+
+namespace dlrm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int RC_LD = BK + 4;              // floats per LDS row of an RC operand
+constexpr int RC_TILE = BM * RC_LD;        // 4608 floats
+
+constexpr int TILE_MAX = RC_TILE;
+constexpr int kGemmThreads = 256;
+
+struct GemmParams {
+    const float *A;
+    int64_t lda;
+    const float *B;
+    int64_t ldb;
+    float *C;
+    int64_t ldc;
+    int M, N, K;          // C is [M,N], reduction length K
+    const float *bias;    // [N] or NULL (added per output column)
+    int relu;             // max(.,0) after the bias
+    const float *mask;    // [M,N] (ld mask_ld) or NULL: C = (mask > 0) ? C : 0
+    int64_t mask_ld;
+    int a_vec, b_vec;     // operand rows are 16-byte aligned: 16-byte global loads allowed
+    int k_per_split;      // reduction elements per blockIdx.z (multiple of BK)
+    int64_t slab_stride;  // elements between the partial outputs of consecutive splits
+};
+
+// Global -> register staging of one operand tile (4 x 16 bytes per thread).
+// RC: tile rows are output indices, 32 reduction elements (128 B) each: 8 lanes per row.
+// RS: tile rows are reduction indices, 128 output elements (512 B) each: 32 lanes per row.
+template <bool RC>
+__device__ inline void load_tile(const float *__restrict__ base, int64_t ld, int o0, int o_end, int r0, int r_end,
+                                 bool vec, float4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int o, r;
+        if constexpr (RC) { o = o0 + (tid >> 3) + 32 * u; r = r0 + (tid & 7) * 4; }
+        else { r = r0 + (tid >> 5) + 8 * u; o = o0 + (tid & 31) * 4; }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (RC) {
+            if (o < o_end) {
+                const float *p = base + (int64_t)o * ld + r;
+                if (vec && r + 3 < r_end) v = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (r < r_end) v.x = p[0];
+                    if (r + 1 < r_end) v.y = p[1];
+                    if (r + 2 < r_end) v.z = p[2];
+                    if (r + 3 < r_end) v.w = p[3];
+                }
+            }
+        } else {
+            if (r < r_end) {
+                const float *p = base + (int64_t)r * ld + o;
+                if (vec && o + 3 < o_end) v = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (o < o_end) v.x = p[0];
+                    if (o + 1 < o_end) v.y = p[1];
+                    if (o + 2 < o_end) v.z = p[2];
+                    if (o + 3 < o_end) v.w = p[3];
+                }
+            }
+        }
+        reg[u] = v;
+    }
+}
+
+template <bool RC>
+__device__ inline void store_tile(float *__restrict__ s, const float4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int off;
+        if constexpr (RC) off = ((tid >> 3) + 32 * u) * RC_LD + (tid & 7) * 4;
+        else off = ((tid >> 5) + 8 * u) * BM + (tid & 31) * 4;
+        *reinterpret_cast<float4 *>(s + off) = reg[u];
+    }
+}
+
+// fragment of 4 reduction elements (one per MFMA of a group of four) for the
+// 32 output indices starting at o_base, reduction chunk q (8 elements)
+template <bool RC>
+__device__ inline void load_frag(const float *__restrict__ s, int o_base, int q, float (&f)[4]) {
+    const int lane = threadIdx.x & 63;
+    const int o = o_base + (lane & 31), h = lane >> 5;
+    if constexpr (RC) {
+        const float4 v = *reinterpret_cast<const float4 *>(s + o * RC_LD + q * 8 + h * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) f[j] = s[(q * 8 + h * 4 + j) * BM + o];
+    }
+}
+
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_MAX];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int steps = (k_end - k_begin + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    if (steps > 0) {
+        load_tile<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, p.a_vec, ra);
+        load_tile<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, p.b_vec, rb);
+        store_tile<A_RC>(smem[0][0], ra);
+        store_tile<B_RC>(smem[0][1], rb);
+    }
+    __syncthreads();
+
+    for (int st = 0; st < steps; st++) {
+        const int cur = st & 1;
+        const bool more = st + 1 < steps;
+        if (more) {
+            const int r0 = k_begin + (st + 1) * BK;
+            load_tile<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, p.a_vec, ra);
+            load_tile<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, p.b_vec, rb);
+        }
+        const float *sa = smem[cur][0], *sb = smem[cur][1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float fa[2][4], fb[2][4];
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) load_frag<A_RC>(sa, wr * 64 + mi * 32, q, fa[mi]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) load_frag<B_RC>(sb, wc * 64 + ni * 32, q, fb[ni]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<A_RC>(smem[cur ^ 1][0], ra);
+            store_tile<B_RC>(smem[cur ^ 1][1], rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
+    float *C = p.C + (int64_t)blockIdx.z * p.slab_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+        const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    float v = acc[mi][ni][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask) v = p.mask[(int64_t)m * p.mask_ld + n] > 0.f ? v : 0.f;
+                    C[(int64_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out)
+__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, int64_t stride, int rows, int cols,
+                                    float *__restrict__ out, int64_t ld_out) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < splits; s++) a += slabs[(int64_t)s * stride + i];
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        out[(int64_t)r * ld_out + c] = a;
+    }
+}
+
+// column sums of an [M,N] matrix: one workgroup per 64 columns, partial sums
+// over row slices are combined through LDS; slices across workgroups go to
+// partial[slice][n] and are reduced by reduce_slabs_kernel
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int64_t ld, int M, int N,
+                                                      int rows_per_slice, float *__restrict__ partial) {
+    __shared__ float s[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int m_begin = blockIdx.y * rows_per_slice;
+    const int m_end = min(M, m_begin + rows_per_slice);
+    float a = 0.f;
+    if (n < N)
+        for (int m = m_begin + w; m < m_end; m += 4) a += x[(int64_t)m * ld + n];
+    s[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = s[0][lane] + s[1][lane] + s[2][lane] + s[3][lane];
+}
+
+__global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__ g, int64_t n, float lr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        w[i] -= lr * g[i];
+}
+
+template <bool A_RC, bool B_RC>
+static int launch_gemm(const GemmParams &p, int splits, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.M, BM), (unsigned)splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), grid, dim3(kGemmThreads), 0, s, p);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+// rows of an operand start on 16-byte boundaries (otherwise the kernel falls back to 4-byte loads)
+static int vec_ok(const void *p, int64_t ld) { return aligned16(p) && ld % 4 == 0; }
+
+static int choose_splits(int M_red, int tiles) {
+    // enough workgroups for 256 CUs x 2, each split at least 8 reduction steps deep
+    int want = (int)ceil_div(1024, tiles);
+    int max_by_depth = M_red / (BK * 8);
+    if (max_by_depth < 1) max_by_depth = 1;
+    int s = want < max_by_depth ? want : max_by_depth;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+}  // namespace dlrm
+
+using namespace dlrm;
+
+extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
+    DLRM_REQUIRE(l != nullptr, "linear descriptor is NULL");
+    DLRM_REQUIRE(l->M >= 0 && l->N >= 1 && l->K >= 1, "bad shape M=%lld N=%d K=%d", (long long)l->M, l->N, l->K);
+    if (l->M == 0) return DLRM_OK;
+    DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
+    DLRM_REQUIRE(l->d_x && l->d_w && l->d_y, "NULL operand");
+    DLRM_REQUIRE(l->x_ld >= l->K && l->w_ld >= l->K && l->y_ld >= l->N, "leading dimension too small");
+    GemmParams p{};
+    p.A = l->d_x; p.lda = l->x_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_y; p.ldc = l->y_ld;
+    p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
+    p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
+    p.k_per_split = (int)ceil_div(l->K, BK) * BK;
+    return launch_gemm<true, true>(p, 1, as_stream(stream));
+}
+
+extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream) {
+    DLRM_REQUIRE(l != nullptr, "linear_bwd descriptor is NULL");
+    DLRM_REQUIRE(l->M >= 0 && l->N >= 1 && l->K >= 1, "bad shape");
+    if (l->M == 0) return DLRM_OK;
+    DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
+    DLRM_REQUIRE(l->d_dz && l->d_w && l->d_dx, "NULL operand");
+    DLRM_REQUIRE(l->dz_ld >= l->N && l->w_ld >= l->K && l->dx_ld >= l->K, "leading dimension too small");
+    GemmParams p{};
+    p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_dx; p.ldc = l->dx_ld;
+    p.M = (int)l->M; p.N = l->K; p.K = l->N;  // C = dx [M,K], reduction over N
+    p.mask = l->d_relu_mask; p.mask_ld = l->relu_mask_ld;
+    p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
+    p.k_per_split = (int)ceil_div(l->N, BK) * BK;
+    return launch_gemm<true, false>(p, 1, as_stream(stream));
+}
+
+extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes) {
+    DLRM_REQUIRE(bytes != nullptr && M >= 0 && N >= 1 && K >= 1, "bad arguments");
+    const int tiles = (int)(ceil_div(N, BM) * ceil_div(K, BN));
+    const int splits = choose_splits((int)M, tiles);
+    const int slices = (int)ceil_div(M > 0 ? M : 1, 2048);
+    *bytes = sizeof(float) * ((size_t)splits * N * K + (size_t)slices * N) + 256;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
+                                           dlrm_stream_t stream) {
+    DLRM_REQUIRE(l != nullptr, "linear_bwd descriptor is NULL");
+    DLRM_REQUIRE(l->M >= 1 && l->N >= 1 && l->K >= 1, "bad shape");
+    DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
+    DLRM_REQUIRE(l->d_dz && l->d_x && l->d_dw, "NULL operand");
+    DLRM_REQUIRE(l->dz_ld >= l->N && l->x_ld >= l->K && l->dw_ld >= l->K, "leading dimension too small");
+    size_t need = 0;
+    dlrm_linear_backward_weight_workspace_bytes(l->M, l->N, l->K, &need);
+    DLRM_REQUIRE(d_workspace != nullptr && workspace_bytes >= need, "workspace too small: %zu < %zu", workspace_bytes,
+                 need);
+    DLRM_REQUIRE(aligned16(d_workspace), "workspace must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const int tiles = (int)(ceil_div(l->N, BM) * ceil_div(l->K, BN));
+    const int splits = choose_splits((int)l->M, tiles);
+    float *slabs = static_cast<float *>(d_workspace);
+    GemmParams p{};
+    p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_x; p.ldb = l->x_ld;
+    p.M = l->N; p.N = l->K; p.K = (int)l->M;  // C = dW [N,K], reduction over the batch
+    p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
+    p.k_per_split = (int)ceil_div(ceil_div(l->M, splits), BK) * BK;
+    if (splits == 1) {
+        p.C = l->d_dw; p.ldc = l->dw_ld;
+        if (int rc = launch_gemm<false, false>(p, 1, s)) return rc;
+    } else {
+        p.C = slabs; p.ldc = l->K; p.slab_stride = (int64_t)l->N * l->K;
+        const int real_splits = (int)ceil_div(l->M, p.k_per_split);
+        if (int rc = launch_gemm<false, false>(p, real_splits, s)) return rc;
+        const int64_t n = (int64_t)l->N * l->K;
+        const unsigned blocks = (unsigned)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, real_splits, p.slab_stride,
+                           l->N, l->K, l->d_dw, l->dw_ld);
+        DLRM_LAUNCH_CHECK();
+    }
+    if (l->d_db) {
+        float *partial = slabs + (size_t)splits * l->N * l->K;
+        const int slices = (int)ceil_div(l->M, 2048);
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(l->N, 64), (unsigned)slices), dim3(256), 0, s,
+                           l->d_dz, l->dz_ld, (int)l->M, l->N, 2048, partial);
+        DLRM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 256)), dim3(256), 0, s, partial, slices,
+                           (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
+        DLRM_LAUNCH_CHECK();
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_sgd_step(float *d_w, const float *d_g, int64_t n, float lr, dlrm_stream_t stream) {
+    DLRM_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_w && d_g, "NULL operand");
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d_w, d_g, n, lr);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}

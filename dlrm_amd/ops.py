@@ -123,3 +123,133 @@ def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, 
     check(_capi.lib().dlrm_embbag_backward_update(C.byref(d), _ptr(grad), C.c_int64(grad_ld), C.byref(o),
                                                   _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
     return workspace
+
+
+# ------------------------------------------------------------------ dense
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"
+    return t.stride(0)
+
+
+def linear_forward(x, w, bias, relu, out=None):
+    """y = act(x W^T + b).  x [M,K] and w [N,K] may be column slices of wider
+    (padded) buffers: the row stride is passed as the leading dimension."""
+    _require_cuda(x, w, bias, out)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == torch.float32 and w.dtype == torch.float32
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    d = _capi.LinearDesc()
+    d.M, d.N, d.K = M, N, K
+    d.d_x, d.x_ld = x.data_ptr(), _ld(x)
+    d.d_w, d.w_ld = w.data_ptr(), _ld(w)
+    d.d_bias = 0 if bias is None else bias.data_ptr()
+    d.d_y, d.y_ld = out.data_ptr(), _ld(out)
+    d.act = _capi.ACT_RELU if relu else _capi.ACT_NONE
+    check(_capi.lib().dlrm_linear_forward(C.byref(d), _stream()))
+    return out
+
+
+def linear_backward_data(dz, w, relu_mask=None, out=None):
+    """dx = dz W, optionally masked with (relu_mask > 0)."""
+    _require_cuda(dz, w, relu_mask, out)
+    M, N = dz.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+    d = _capi.LinearBwdDesc()
+    d.M, d.N, d.K = M, N, K
+    d.d_dz, d.dz_ld = dz.data_ptr(), _ld(dz)
+    d.d_w, d.w_ld = w.data_ptr(), _ld(w)
+    d.d_dx, d.dx_ld = out.data_ptr(), _ld(out)
+    if relu_mask is not None:
+        d.d_relu_mask, d.relu_mask_ld = relu_mask.data_ptr(), _ld(relu_mask)
+    check(_capi.lib().dlrm_linear_backward_data(C.byref(d), _stream()))
+    return out
+
+
+def linear_backward_weight_workspace_bytes(M, N, K):
+    n = C.c_size_t(0)
+    check(_capi.lib().dlrm_linear_backward_weight_workspace_bytes(C.c_int64(M), N, K, C.byref(n)))
+    return int(n.value)
+
+
+def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True):
+    """dW = dz^T x [N,K], db = column sums of dz."""
+    _require_cuda(dz, x, dw, db, workspace)
+    M, N = dz.shape
+    K = x.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    if db is None and want_db:
+        db = torch.empty((N,), dtype=torch.float32, device=dz.device)
+    need = linear_backward_weight_workspace_bytes(M, N, K)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dz.device)
+    d = _capi.LinearBwdDesc()
+    d.M, d.N, d.K = M, N, K
+    d.d_dz, d.dz_ld = dz.data_ptr(), _ld(dz)
+    d.d_x, d.x_ld = x.data_ptr(), _ld(x)
+    d.d_dw, d.dw_ld = dw.data_ptr(), _ld(dw)
+    d.d_db = 0 if db is None else db.data_ptr()
+    check(_capi.lib().dlrm_linear_backward_weight(C.byref(d), _ptr(workspace), C.c_size_t(workspace.numel()),
+                                                  _stream()))
+    return dw, db, workspace
+
+
+def sgd_step_(w, g, lr):
+    _require_cuda(w, g)
+    assert w.is_contiguous() and g.is_contiguous() and w.numel() == g.numel()
+    check(_capi.lib().dlrm_sgd_step(_ptr(w), _ptr(g), C.c_int64(w.numel()), C.c_float(lr), _stream()))
+    return w
+
+
+# ------------------------------------------------- interaction and losses
+
+
+def interact_dot_forward(x, out=None, out_ld=None):
+    """x [B,F,D] -> [B, D + F(F-1)/2] (row stride out_ld, tail zero-filled)."""
+    _require_cuda(x, out)
+    B, F, D = x.shape
+    assert x.is_contiguous()
+    n_out = D + F * (F - 1) // 2
+    if out is None:
+        out_ld = n_out if out_ld is None else out_ld
+        out = torch.empty((B, out_ld), dtype=torch.float32, device=x.device)
+    check(_capi.lib().dlrm_interact_dot_forward(_ptr(x), C.c_int64(B), F, D, _ptr(out), C.c_int64(out_ld), _stream()))
+    return out
+
+
+def interact_dot_backward(x, dout, relu_mask_feature0=False, out=None):
+    _require_cuda(x, dout, out)
+    B, F, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_capi.lib().dlrm_interact_dot_backward(_ptr(x), _ptr(dout), C.c_int64(_ld(dout)), C.c_int64(B), F, D,
+                                                 _ptr(out), int(relu_mask_feature0), _stream()))
+    return out
+
+
+def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None):
+    _require_cuda(pred, target)
+    n = pred.numel()
+    assert pred.is_contiguous() and target.is_contiguous() and target.numel() == n
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device) if loss is None else loss
+    dpred = torch.empty_like(pred) if dpred is None else dpred
+    check(_capi.lib().dlrm_loss_mse(_ptr(pred), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss), _ptr(dpred),
+                                    int(relu_mask_pred), _stream()))
+    return loss, dpred
+
+
+def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None):
+    _require_cuda(logit, target)
+    n = logit.numel()
+    assert logit.is_contiguous() and target.is_contiguous() and target.numel() == n
+    loss = torch.empty(1, dtype=torch.float32, device=logit.device) if loss is None else loss
+    dlogit = torch.empty_like(logit) if dlogit is None else dlogit
+    check(_capi.lib().dlrm_loss_bce_logits(_ptr(logit), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss),
+                                           _ptr(dlogit), _stream()))
+    return loss, dlogit

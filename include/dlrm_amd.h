@@ -125,6 +125,112 @@ int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_grad, int64
                                 const dlrm_sparse_opt *opt, void *d_workspace,
                                 size_t workspace_bytes, dlrm_stream_t stream);
 
+/* ------------------------------------------------------------- dense MLP */
+
+/*
+ * y = act(x W^T + bias): one torch::nn::Linear + torch::relu of Net2::forward
+ * (src/dlrmtest.cpp:254-272; layers made by create_fc, :119-140).  W is [N,K]
+ * row-major (torch layout).  float32 on the matrix cores
+ * (v_mfma_f32_32x32x2_f32), so results are an exact-f32 k-ordered fma chain.
+ * Any shape and leading dimension is accepted (K = 13, 479, ...); operands whose
+ * rows start on 16-byte boundaries (pointer 16-byte aligned, leading dimension
+ * a multiple of 4 floats) are read with 16-byte loads, others with 4-byte loads.
+ */
+typedef struct dlrm_linear {
+    int64_t M;          /* rows of x (batch) */
+    int32_t N, K;       /* out features, in features */
+    const float *d_x;   /* [M,K] */
+    int64_t x_ld;
+    const float *d_w;   /* [N,K] */
+    int64_t w_ld;
+    const float *d_bias; /* [N] or NULL */
+    float *d_y;         /* [M,N] */
+    int64_t y_ld;
+    int32_t act;        /* DLRM_ACT_NONE | DLRM_ACT_RELU */
+} dlrm_linear;
+
+int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream);
+
+/*
+ * Backward of the same layer; replaces the autograd pass loss.backward()
+ * (src/dlrmtest.cpp:531) for the MLP.  dz is the gradient w.r.t. the
+ * pre-activation z = x W^T + b.
+ *   backward_data  : dx = dz W, then, if d_relu_mask != NULL,
+ *                    dx = (relu_mask > 0) ? dx : 0  -- relu_mask is the output
+ *                    of the previous layer (= this layer's x), which turns dx
+ *                    directly into the previous layer's dz.
+ *   backward_weight: dW = dz^T x  [N,K] and, if d_db != NULL, db = column
+ *                    sums of dz.  The reduction over the batch is split over
+ *                    workgroups; partial sums go through d_workspace
+ *                    (dlrm_linear_backward_weight_workspace_bytes) and are
+ *                    combined in a fixed order (reproducible).
+ */
+typedef struct dlrm_linear_bwd {
+    int64_t M;
+    int32_t N, K;
+    const float *d_dz;  /* [M,N] */
+    int64_t dz_ld;
+    const float *d_w;   /* [N,K]  (backward_data) */
+    int64_t w_ld;
+    const float *d_x;   /* [M,K]  (backward_weight) */
+    int64_t x_ld;
+    float *d_dx;        /* [M,K]  (backward_data) */
+    int64_t dx_ld;
+    const float *d_relu_mask; /* [M,K] or NULL (backward_data) */
+    int64_t relu_mask_ld;
+    float *d_dw;        /* [N,K]  (backward_weight) */
+    int64_t dw_ld;
+    float *d_db;        /* [N] or NULL (backward_weight) */
+} dlrm_linear_bwd;
+
+int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream);
+int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes);
+int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
+                                dlrm_stream_t stream);
+
+/*
+ * w -= lr * g on a dense tensor.  Replaces torch::optim::SGD::step
+ * (src/dlrmtest.cpp:505-506, :533); the reference builds a new optimizer every
+ * batch, so its momentum buffer never carries over and the step is plain SGD.
+ */
+int dlrm_sgd_step(float *d_w, const float *d_g, int64_t n, float lr, dlrm_stream_t stream);
+
+/* ------------------------------------------------- interaction and losses */
+
+/*
+ * Pairwise dot interaction (absent from the reference, whose interaction is
+ * torch::cat, src/dlrmtest.cpp:265; required for the Criteo shapes):
+ *   x [B, F, D] (feature 0 = bottom-MLP output, 1..F-1 = pooled embeddings)
+ *   out[b] = [ x[b][0][0..D) , <x[b][i], x[b][j]> for i in 1..F-1, j in 0..i-1 ]
+ *   out row length D + F(F-1)/2, row stride out_ld (pad columns are zeroed up
+ *   to out_ld so the result can feed dlrm_linear_forward directly).
+ * backward: dx = d(dense copy) + (S + S^T) x with S the strict lower triangle
+ * of the pair gradients; if relu_mask_feature0 != 0 the gradient of feature 0
+ * is masked with (x[b][0] > 0), which makes it the bottom MLP's last dz.
+ */
+int dlrm_interact_dot_forward(const float *d_x, int64_t B, int32_t F, int32_t D, float *d_out, int64_t out_ld,
+                              dlrm_stream_t stream);
+int dlrm_interact_dot_backward(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F,
+                               int32_t D, float *d_dx, int32_t relu_mask_feature0, dlrm_stream_t stream);
+
+/*
+ * Loss forward + backward in one pass, mean reduction over n predictions.
+ *   mse : torch::mse_loss (src/dlrmtest.cpp:522);  d_dpred = 2 (pred - target) / n
+ *   bce : binary cross entropy with logits (MLPerf DLRM loss; not in the
+ *         reference);  d_dpred = (sigmoid(pred) - target) / n
+ * If relu_mask_pred != 0, d_dpred is additionally zeroed where pred <= 0 (the
+ * reference applies ReLU to the last layer too, src/dlrmtest.cpp:270, so pred
+ * is a ReLU output and this yields the last layer's dz).
+ * d_loss receives the scalar loss (device float); preds/targets have stride 1.
+ * mean_over is the divisor of the mean: n on one GPU; the GLOBAL batch when the
+ * batch is sharded over ranks, so that per-rank losses and gradients simply add
+ * up to those of the whole batch.
+ */
+int dlrm_loss_mse(const float *d_pred, const float *d_target, int64_t n, int64_t mean_over, float *d_loss,
+                  float *d_dpred, int32_t relu_mask_pred, dlrm_stream_t stream);
+int dlrm_loss_bce_logits(const float *d_logit, const float *d_target, int64_t n, int64_t mean_over,
+                         float *d_loss, float *d_dlogit, dlrm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,148 @@
+"""MLP GEMMs (fp32 MFMA), dot interaction and losses: HIP kernels vs the CPU
+oracle (double accumulation).
+
+Tolerance: 1e-5 relative to the largest |reference| value of each tensor.  The
+MFMA path is a k-ordered fp32 fma chain; for the deepest reductions used here
+(K = 1024 forward, batch = 2048 in the weight gradient) its rounding error
+relative to the tensor scale stays below that bound on N(0,1) data."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_embbag_forward_gpu import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # M, N, K
+    (60, 128, 256),     # reference RMC1 bottom layer 1 (batch 60)
+    (60, 32, 128),
+    (60, 32, 1056),
+    (60, 1, 32),
+    (257, 512, 13),     # Criteo bottom layer 1: K = 13
+    (300, 1024, 479),   # MLPerf top layer 1: K = 479 (odd)
+    (2048, 256, 512),
+    (130, 130, 130),    # nothing a multiple of the tile
+    (1, 7, 5),
+]
+
+
+def padded(a, mult=4):
+    """copy of a 2-D array into a buffer whose row stride is a multiple of 4 floats"""
+    r, c = a.shape
+    ld = (c + mult - 1) // mult * mult
+    buf = torch.zeros((r, ld), dtype=torch.float32, device="cuda")
+    buf[:, :c] = torch.from_numpy(a).cuda()
+    return buf[:, :c]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_forward(oracle, M, N, K, relu):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = oracle.linear_forward(x, w, b, relu)
+    y = ops.linear_forward(padded(x), padded(w), torch.from_numpy(b).cuda(), relu)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_backward(oracle, M, N, K, relu):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M * 5 + N * 11 + K)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)  # x is a ReLU output
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    y = oracle.linear_forward(x, w, b, relu)
+    dx_ref, dw_ref, db_ref = oracle.linear_backward(x, w, y, dy, relu)
+    dz = dy * (y > 0) if relu else dy
+    # the oracle's dx is w.r.t. x; the kernel can additionally apply the ReLU mask of the layer below
+    dxm_ref = dx_ref * (x > 0)
+    d_dz, d_x, d_w = padded(dz.astype(np.float32)), padded(x), padded(w)
+    dx = ops.linear_backward_data(d_dz, d_w)
+    dxm = ops.linear_backward_data(d_dz, d_w, relu_mask=d_x)
+    dw, db, _ = ops.linear_backward_weight(d_dz, d_x)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5
+    assert rel_err(dxm.cpu().numpy(), dxm_ref) <= 1e-5
+    assert rel_err(dw.cpu().numpy(), dw_ref) <= 1e-5
+    assert rel_err(db.cpu().numpy(), db_ref) <= 1e-5
+
+
+def test_backward_weight_large_batch_split(oracle):
+    """batch large enough that the reduction is split over workgroups"""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(3)
+    M, N, K = 8192, 64, 96
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    dz = rng.standard_normal((M, N)).astype(np.float32)
+    w = np.zeros((N, K), np.float32)
+    _, dw_ref, db_ref = oracle.linear_backward(x, w, np.ones((M, N), np.float32), dz, False, need_dx=False)
+    dw, db, _ = ops.linear_backward_weight(padded(dz), padded(x))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().numpy(), dw_ref) <= 1e-5
+    assert rel_err(db.cpu().numpy(), db_ref) <= 1e-5
+
+
+def test_sgd_step(oracle):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal(10007).astype(np.float32)
+    g = rng.standard_normal(10007).astype(np.float32)
+    dw = torch.from_numpy(w).cuda()
+    ops.sgd_step_(dw, torch.from_numpy(g).cuda(), 0.01)
+    oracle.sgd_step(w, g, 0.01)
+    assert rel_err(dw.cpu().numpy(), w) <= 1e-6
+
+
+@pytest.mark.parametrize("B,F,D", [(5, 27, 128), (64, 27, 16), (3, 4, 8), (130, 32, 64), (7, 1, 32), (9, 2, 256)])
+def test_interact_dot(oracle, B, F, D):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(B + F + D)
+    x = rng.standard_normal((B, F, D)).astype(np.float32)
+    x[:, 0, :] = np.maximum(x[:, 0, :], 0)
+    ref = oracle.interact_dot_forward(x)
+    n_out = ref.shape[1]
+    ld = (n_out + 3) // 4 * 4 + 4
+    dxd = torch.from_numpy(x).cuda()
+    out = ops.interact_dot_forward(dxd, out_ld=ld)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert rel_err(got[:, :n_out], ref) <= 1e-5
+    assert (got[:, n_out:] == 0).all()
+    dout = rng.standard_normal((B, n_out)).astype(np.float32)
+    dref = oracle.interact_dot_backward(x, dout)
+    d_dout = torch.zeros((B, ld), device="cuda")
+    d_dout[:, :n_out] = torch.from_numpy(dout).cuda()
+    dx = ops.interact_dot_backward(dxd, d_dout[:, :n_out])
+    dxm = ops.interact_dot_backward(dxd, d_dout[:, :n_out], relu_mask_feature0=True)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu().numpy(), dref) <= 1e-5
+    dref_m = dref.copy()
+    dref_m[:, 0, :] *= (x[:, 0, :] > 0)
+    assert rel_err(dxm.cpu().numpy(), dref_m) <= 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 60, 2048, 65536])
+def test_losses(oracle, n):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(n)
+    pred = (rng.standard_normal(n) * 3).astype(np.float32)
+    tgt = rng.standard_normal(n).astype(np.float32)
+    lab = (rng.random(n) < 0.3).astype(np.float32)
+    l_ref, d_ref = oracle.mse_loss(pred, tgt)
+    l, d = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda())
+    assert abs(l.item() - l_ref) <= 1e-5 * abs(l_ref)
+    assert rel_err(d.cpu().numpy(), d_ref) <= 1e-5
+    _, dm = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True)
+    assert rel_err(dm.cpu().numpy(), d_ref * (pred > 0)) <= 1e-5
+    l_ref, d_ref = oracle.bce_logits_loss(pred, lab)
+    l, d = ops.loss_bce_logits(torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda())
+    assert abs(l.item() - l_ref) <= 1e-5 * abs(l_ref)
+    assert rel_err(d.cpu().numpy(), d_ref) <= 1e-5
