@@ -30,6 +30,17 @@ __global__ void table_init_uniform_kernel(T *dst, int64_t n, uint64_t seed, int6
     }
 }
 
+// one thread per 16 bytes when both sides allow it, else per float
+template <typename V>
+__global__ void copy_2d_kernel(V *__restrict__ dst, int64_t dst_ld, const V *__restrict__ src, int64_t src_ld,
+                               int64_t rows, int64_t cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
 }  // namespace dlrm
 
 using namespace dlrm;
@@ -53,6 +64,26 @@ extern "C" int dlrm_table_init_uniform(void *dst, int row_dtype, int64_t n, uint
     else
         hipLaunchKernelGGL(table_init_uniform_kernel<uint16_t>, dim3(blocks), dim3(threads), 0,
                            as_stream(stream), static_cast<uint16_t *>(dst), n, seed, first);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_copy_2d(float *d_dst, int64_t dst_ld, const float *d_src, int64_t src_ld, int64_t rows,
+                            int64_t cols, dlrm_stream_t stream) {
+    DLRM_REQUIRE(rows >= 0 && cols >= 0 && dst_ld >= cols && src_ld >= cols, "bad 2-D copy shape");
+    if (rows == 0 || cols == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_dst && d_src, "NULL operand");
+    const bool v4 = cols % 4 == 0 && dst_ld % 4 == 0 && src_ld % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(d_dst) % 16 == 0 && reinterpret_cast<uintptr_t>(d_src) % 16 == 0;
+    const int64_t n = v4 ? rows * cols / 4 : rows * cols;
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    if (v4)
+        hipLaunchKernelGGL(copy_2d_kernel<float4>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<float4 *>(d_dst), dst_ld / 4, reinterpret_cast<const float4 *>(d_src),
+                           src_ld / 4, rows, cols / 4);
+    else
+        hipLaunchKernelGGL(copy_2d_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), d_dst, dst_ld, d_src,
+                           src_ld, rows, cols);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

@@ -1,0 +1,358 @@
+"""DLRM train / inference step on one MI355X or table-wise sharded over a node.
+
+Host-side mirror of the reference's model interface (dlrm_libtorch/src/dlrmtest.cpp):
+  struct emb   (:144-210)  -> DLRM.embedding_forward / embedding_backward_update
+  struct Net2  (:217-278)  -> DLRM.bottom / DLRM.top  (MLPStack)
+  main loop    (:473-545)  -> DLRM.train_step
+Everything numeric runs in the HIP kernels of libdlrm_amd.so through the C ABI
+(dlrm_amd.ops); torch provides device buffers, streams and, when the model is
+sharded, the RCCL collectives (torch.distributed, backend "nccl").
+
+Sharding (world > 1): every rank owns whole tables (sharding.plan_table_wise)
+and looks them up for the GLOBAL batch; pooled vectors go to the rank that owns
+each batch slice with one all-to-all, their gradients come back with another;
+the MLPs are data parallel and their gradients are summed with one all-reduce
+of a single flat buffer.  Losses are means over the global batch, so per-rank
+gradients simply add.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _capi, ops
+from .sharding import ShardingPlan, plan_table_wise
+
+# Criteo Terabyte cardinalities with the MLPerf 40M row cap (public MLPerf DLRM spec)
+MLPERF_TABLE_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10,
+                     2208, 11938, 155, 4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+# Criteo Kaggle (Display Advertising Challenge) cardinalities
+KAGGLE_TABLE_ROWS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27,
+                     14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+@dataclass
+class DLRMConfig:
+    table_rows: List[int]
+    dim: int
+    dense_in: int
+    bottom: List[int]             # bottom MLP layer widths (every layer ReLU)
+    top: List[int]                # top MLP layer widths, last = 1
+    interaction: str = "dot"      # "dot" | "cat" (the reference concatenates, src/dlrmtest.cpp:265)
+    loss: str = "bce"             # "bce" | "mse" (reference: mse, :522)
+    final_relu: bool = False      # reference applies ReLU to the last layer too (:270)
+    pooling: str = "sum"          # "sum" | "mean"
+    lookups: int = 1              # rows pooled per bag in the synthetic batches
+    row_dtype: str = "f32"        # "f32" | "bf16"
+    emb_optimizer: str = "sgd"    # "sgd" | "adagrad"
+    lr: float = 0.01
+    eps: float = 1e-8
+    name: str = "custom"
+
+    @staticmethod
+    def mlperf(**kw):
+        return DLRMConfig(table_rows=list(MLPERF_TABLE_ROWS), dim=128, dense_in=13, bottom=[512, 256, 128],
+                          top=[1024, 1024, 512, 256, 1], name="mlperf-dlrm-criteo-tb-40M", **kw)
+
+    @staticmethod
+    def kaggle(**kw):
+        return DLRMConfig(table_rows=list(KAGGLE_TABLE_ROWS), dim=16, dense_in=13, bottom=[512, 256, 64, 16],
+                          top=[512, 256, 1], name="criteo-kaggle", **kw)
+
+    @staticmethod
+    def rmc1(rows=500000, **kw):
+        """The reference's default synthetic model (src/dlrmtest.cpp:37-49, :234-242)."""
+        return DLRMConfig(table_rows=[rows] * 32, dim=32, dense_in=256, bottom=[128, 32], top=[32, 1],
+                          interaction="cat", loss="mse", final_relu=True, pooling="mean", lookups=80,
+                          name="rmc1", **kw)
+
+    @property
+    def num_tables(self):
+        return len(self.table_rows)
+
+    @property
+    def num_features(self):
+        return self.num_tables + 1
+
+    @property
+    def top_in(self):
+        if self.interaction == "dot":
+            F = self.num_features
+            return self.dim + F * (F - 1) // 2
+        return self.bottom[-1] + self.num_tables * self.dim
+
+    def flops_per_sample_fwd(self):
+        f = 0
+        k = self.dense_in
+        for n in self.bottom:
+            f += 2 * k * n
+            k = n
+        k = self.top_in
+        for n in self.top:
+            f += 2 * k * n
+            k = n
+        if self.interaction == "dot":
+            f += 2 * self.num_features ** 2 * self.dim
+        return f
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class MLPStack:
+    """A stack of Linear+ReLU layers (struct Net2's fc1..fc4, src/dlrmtest.cpp:234-272).
+    Weights [N, pad4(K)] and biases live in one flat parameter buffer shared by
+    all stacks of a model; gradients in its twin."""
+
+    def __init__(self, sizes, params, grads, offset, last_relu=True):
+        self.sizes = list(sizes)
+        self.last_relu = last_relu
+        self.W, self.b, self.dW, self.db = [], [], [], []
+        o = offset
+        for K, N in zip(sizes[:-1], sizes[1:]):
+            kp = _pad4(K)
+            self.W.append(params[o:o + N * kp].view(N, kp)[:, :K])
+            self.dW.append(grads[o:o + N * kp].view(N, kp)[:, :K])
+            o += N * kp
+            self.b.append(params[o:o + N])
+            self.db.append(grads[o:o + N])
+            o += _pad4(N)
+        self.end = o
+
+    @staticmethod
+    def param_count(sizes):
+        return sum(N * _pad4(K) + _pad4(N) for K, N in zip(sizes[:-1], sizes[1:]))
+
+    @property
+    def n_layers(self):
+        return len(self.W)
+
+    def init_(self, gen):
+        """Xavier-style normal init (DLRM convention); the reference uses
+        unscaled randn weights (src/dlrmtest.cpp:110-113), which tests pass in
+        explicitly."""
+        for W, b in zip(self.W, self.b):
+            N, K = W.shape
+            W.copy_((torch.randn(N, K, generator=gen) * (2.0 / (K + N)) ** 0.5).to(W.device))
+            b.copy_((torch.randn(N, generator=gen) * (1.0 / N) ** 0.5).to(b.device))
+
+    def forward(self, x, acts):
+        """acts[i] receives the output of layer i ([B, N_i] views)."""
+        for i in range(self.n_layers):
+            relu = self.last_relu or i + 1 < self.n_layers
+            ops.linear_forward(x, self.W[i], self.b[i], relu, out=acts[i])
+            x = acts[i]
+        return x
+
+    def backward(self, x_in, acts, dz_last, dz_bufs, ws, dx_first=None):
+        """dz_last: gradient w.r.t. the last layer's pre-activation.  dz_bufs[i]
+        ([B, N_i]) receives the pre-activation gradient of layer i for
+        i < last.  If dx_first is given it receives d(loss)/d(x_in), unmasked."""
+        dz = dz_last
+        for i in reversed(range(self.n_layers)):
+            x = x_in if i == 0 else acts[i - 1]
+            _, _, ws = ops.linear_backward_weight(dz, x, dw=self.dW[i], db=self.db[i], workspace=ws)
+            if i > 0:
+                dz = ops.linear_backward_data(dz, self.W[i], relu_mask=acts[i - 1], out=dz_bufs[i - 1])
+            elif dx_first is not None:
+                ops.linear_backward_data(dz, self.W[0], out=dx_first)
+        return ws
+
+
+class DLRM:
+    def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
+                 seed=0, process_group=None, init_tables=True):
+        """batch: LOCAL batch size (samples whose MLP runs on this rank)."""
+        _capi.lib()  # fail loudly if the HIP library is missing
+        self.cfg, self.B, self.rank, self.world, self.pg = cfg, batch, rank, world, process_group
+        self.Bg = batch * world
+        self.dev = torch.device(device)
+        self.plan = plan or plan_table_wise(cfg.table_rows, world, cfg.dim, 2 if cfg.row_dtype == "bf16" else 4)
+        self.my_tables = self.plan.local_tables(rank)
+        self.Tl = len(self.my_tables)
+        T, D, F = cfg.num_tables, cfg.dim, cfg.num_features
+        dev = self.dev
+        self.pooling = _capi.POOL_MEAN if cfg.pooling == "mean" else _capi.POOL_SUM
+        if cfg.interaction == "dot" and cfg.bottom[-1] != D:
+            raise ValueError("dot interaction needs bottom[-1] == dim")
+
+        # ---- embedding tables of this rank, one allocation, table-major
+        rows = [cfg.table_rows[t] for t in self.my_tables]
+        tro = [0]
+        for r in rows:
+            tro.append(tro[-1] + r)
+        self.total_rows = tro[-1]
+        self.table_row_offsets = torch.tensor(tro, dtype=torch.int64, device=dev)
+        wdtype = torch.bfloat16 if cfg.row_dtype == "bf16" else torch.float32
+        self.weight = torch.empty((max(self.total_rows, 1), D), dtype=wdtype, device=dev)
+        if init_tables and self.total_rows:
+            # every table is its own stream of uniform [0,1) values, keyed by the GLOBAL
+            # table id, so a sharded model holds the same numbers as a single-GPU one
+            for lt, t in enumerate(self.my_tables):
+                ops.table_init_uniform_(self.weight[tro[lt]:tro[lt + 1]], seed=(seed << 20) + 7919 * (t + 1))
+        self.opt_state = None
+        if cfg.emb_optimizer == "adagrad":
+            self.opt_state = torch.zeros(max(self.total_rows, 1), dtype=torch.float32, device=dev)
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        # ---- dense parameters: one flat buffer (+ twin for gradients)
+        bsz = [cfg.dense_in] + list(cfg.bottom)
+        tsz = [cfg.top_in] + list(cfg.top)
+        n_par = MLPStack.param_count(bsz) + MLPStack.param_count(tsz)
+        self.params = torch.zeros(n_par, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n_par, dtype=torch.float32, device=dev)
+        self.bottom = MLPStack(bsz, self.params, self.grads, 0, last_relu=True)
+        self.top = MLPStack(tsz, self.params, self.grads, self.bottom.end, last_relu=cfg.final_relu)
+        gen = torch.Generator().manual_seed(seed)  # same on every rank: replicas start identical
+        self.bottom.init_(gen)
+        self.top.init_(gen)
+
+        # ---- activations
+        B = batch
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x_dense = torch.zeros((B, _pad4(cfg.dense_in)), **f32)
+        self.labels = torch.zeros(B, **f32)
+        if cfg.interaction == "dot":
+            self.feat = torch.zeros((B, F * D), **f32)            # [B, F, D]; feature 0 = bottom output
+            self.dfeat = torch.zeros((B, F * D), **f32)
+            self.inter_ld = _pad4(cfg.top_in)
+            self.inter = torch.zeros((B, self.inter_ld), **f32)
+            self.dinter = torch.zeros((B, self.inter_ld), **f32)
+            self.emb_col0 = D
+        else:
+            self.emb_col0 = cfg.bottom[-1]
+            self.inter_ld = _pad4(cfg.top_in)
+            self.feat = torch.zeros((B, self.inter_ld), **f32)    # [bottom out | pooled tables], read by the top MLP
+            self.dfeat = torch.zeros((B, self.inter_ld), **f32)
+            self.inter, self.dinter = self.feat, self.dfeat
+        self.bot_acts = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
+        self.bot_acts.append(self.feat[:, :cfg.bottom[-1]])
+        self.bot_dz = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
+        self.top_acts = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.top[:-1]]
+        self.pred = torch.zeros((B, 1), **f32)
+        self.top_acts.append(self.pred)
+        self.top_dz = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.top[:-1]]
+        self.dpred = torch.zeros((B, 1), **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.ws_dense = None
+        self.ws_sparse = None
+
+        # ---- exchange buffers (sharded only)
+        if world > 1:
+            self.send_splits = [B * self.Tl * D] * world
+            self.recv_splits = [B * len(self.plan.tables_of_rank[j]) * D for j in range(world)]
+            self.a2a_send = torch.zeros(max(self.Bg * self.Tl * D, 1), **f32)   # [Bg, Tl*D]
+            self.a2a_recv = torch.zeros(max(B * T * D, 1), **f32)               # blocks [B, Tj*D], j = 0..W-1
+            self.g_send = torch.zeros(max(B * T * D, 1), **f32)
+            self.g_recv = torch.zeros(max(self.Bg * self.Tl * D, 1), **f32)
+
+    # ------------------------------------------------------------ embeddings
+
+    def _emb_kwargs(self, indices, offsets):
+        return dict(weight=self.weight, indices=indices, offsets=offsets, batch=self.Bg, num_tables=self.Tl,
+                    table_row_offsets=self.table_row_offsets, pooling=self.pooling, include_last_offset=True,
+                    error_flag=self.err_flag)
+
+    def embedding_forward(self, indices, offsets):
+        """emb::forward (src/dlrmtest.cpp:170-206) for this rank's tables over the
+        global batch, then the exchange that leaves feat[:, emb_col0:] holding
+        the pooled vectors of ALL tables for the local batch."""
+        D, B = self.cfg.dim, self.B
+        if self.world == 1:
+            out = self.feat[:, self.emb_col0:]
+            ops.embbag_forward(out=out, out_ld=self.feat.stride(0), **self._emb_kwargs(indices, offsets))
+            return
+        import torch.distributed as dist
+        if self.Tl:
+            ops.embbag_forward(out=self.a2a_send, out_ld=self.Tl * D, **self._emb_kwargs(indices, offsets))
+        dist.all_to_all_single(self.a2a_recv, self.a2a_send, self.recv_splits, self.send_splits, group=self.pg)
+        o = 0
+        for j in range(self.world):
+            first, cnt = self.plan.feature_slot(j)
+            if cnt:
+                blk = self.a2a_recv[o:o + B * cnt * D].view(B, cnt * D)
+                c0 = self.emb_col0 + first * D
+                ops.copy_2d_(self.feat[:, c0:c0 + cnt * D], blk)
+            o += B * cnt * D
+
+    def embedding_backward_update(self, indices, offsets):
+        """autograd of embedding_bag + optimizer step + write-back
+        (src/dlrmtest.cpp:531-535) fused: gradients of the pooled vectors go
+        back to the owning ranks and are applied to the rows."""
+        D, B = self.cfg.dim, self.B
+        cfg = self.cfg
+        kw = dict(optimizer=_capi.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else _capi.OPT_SGD,
+                  lr=cfg.lr, eps=cfg.eps, opt_state=self.opt_state, workspace=self.ws_sparse)
+        if self.world == 1:
+            grad = self.dfeat[:, self.emb_col0:]
+            self.ws_sparse = ops.embbag_backward_update(grad=grad, grad_ld=self.dfeat.stride(0),
+                                                        **self._emb_kwargs(indices, offsets), **kw)
+            return
+        import torch.distributed as dist
+        o = 0
+        for j in range(self.world):
+            first, cnt = self.plan.feature_slot(j)
+            if cnt:
+                blk = self.g_send[o:o + B * cnt * D].view(B, cnt * D)
+                c0 = self.emb_col0 + first * D
+                ops.copy_2d_(blk, self.dfeat[:, c0:c0 + cnt * D])
+            o += B * cnt * D
+        dist.all_to_all_single(self.g_recv, self.g_send, self.send_splits, self.recv_splits, group=self.pg)
+        if self.Tl:
+            self.ws_sparse = ops.embbag_backward_update(grad=self.g_recv, grad_ld=self.Tl * D,
+                                                        **self._emb_kwargs(indices, offsets), **kw)
+
+    # ------------------------------------------------------------------ step
+
+    def load_batch(self, dense, labels):
+        self.x_dense[:, :self.cfg.dense_in].copy_(dense)
+        self.labels.copy_(labels.reshape(-1))
+
+    def forward(self, indices, offsets):
+        """Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
+        cfg = self.cfg
+        self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
+        self.embedding_forward(indices, offsets)
+        if cfg.interaction == "dot":
+            ops.interact_dot_forward(self.feat.view(self.B, cfg.num_features, cfg.dim), out=self.inter,
+                                     out_ld=self.inter_ld)
+        self.top.forward(self.inter[:, :cfg.top_in], self.top_acts)
+        return self.pred
+
+    def train_step(self, indices, offsets):
+        """One iteration of the reference's loop body (src/dlrmtest.cpp:505-535):
+        forward, loss, backward, optimizer step on every parameter, sparse
+        row update.  Returns the device scalar holding this rank's share of the
+        global-mean loss."""
+        cfg = self.cfg
+        self.forward(indices, offsets)
+        if cfg.loss == "bce":
+            ops.loss_bce_logits(self.pred.view(-1), self.labels, loss=self.loss, dlogit=self.dpred.view(-1),
+                                mean_over=self.Bg)
+        else:
+            ops.loss_mse(self.pred.view(-1), self.labels, relu_mask_pred=cfg.final_relu, loss=self.loss,
+                         dpred=self.dpred.view(-1), mean_over=self.Bg)
+        # top MLP
+        if cfg.interaction == "dot":
+            self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
+                                              self.ws_dense, dx_first=self.dinter[:, :cfg.top_in])
+            ops.interact_dot_backward(self.feat.view(self.B, cfg.num_features, cfg.dim), self.dinter[:, :cfg.top_in],
+                                      relu_mask_feature0=True, out=self.dfeat.view(self.B, cfg.num_features, cfg.dim))
+        else:
+            self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
+                                              self.ws_dense, dx_first=None)
+            nb = cfg.bottom[-1]
+            dz0 = self.top_dz[0] if self.top.n_layers > 1 else self.dpred
+            # bottom part of the concatenation is a ReLU output, the pooled part is not
+            ops.linear_backward_data(dz0, self.top.W[0][:, :nb], relu_mask=self.feat[:, :nb], out=self.dfeat[:, :nb])
+            ops.linear_backward_data(dz0, self.top.W[0][:, nb:], out=self.dfeat[:, nb:cfg.top_in])
+        # sparse rows (exchange + fused update), then bottom MLP
+        self.embedding_backward_update(indices, offsets)
+        self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
+                                             self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, group=self.pg)
+        ops.sgd_step_(self.params, self.grads, cfg.lr)
+        return self.loss

@@ -253,3 +253,12 @@ def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None):
     check(_capi.lib().dlrm_loss_bce_logits(_ptr(logit), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss),
                                            _ptr(dlogit), _stream()))
     return loss, dlogit
+
+
+def copy_2d_(dst, src):
+    """dst[:, :] = src[:, :] for two row-major 2-D float32 views (any row strides)."""
+    _require_cuda(dst, src)
+    assert dst.shape == src.shape and dst.dtype == torch.float32 and src.dtype == torch.float32
+    check(_capi.lib().dlrm_copy_2d(_ptr(dst), C.c_int64(_ld(dst)), _ptr(src), C.c_int64(_ld(src)),
+                                   C.c_int64(dst.shape[0]), C.c_int64(dst.shape[1]), _stream()))
+    return dst

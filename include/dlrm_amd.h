@@ -64,6 +64,15 @@ const char *dlrm_target_arch(void);
 int dlrm_table_init_uniform(void *dst, int row_dtype, int64_t n, uint64_t seed, int64_t first,
                             dlrm_stream_t stream);
 
+/*
+ * Strided 2-D copy of float32: dst[r*dst_ld + c] = src[r*src_ld + c] for
+ * r < rows, c < cols.  Packs / unpacks the per-rank blocks of the pooled
+ * embedding exchange (the reference has no counterpart: it is single process;
+ * its closest relative is the torch::cat at src/dlrmtest.cpp:196).
+ */
+int dlrm_copy_2d(float *d_dst, int64_t dst_ld, const float *d_src, int64_t src_ld, int64_t rows, int64_t cols,
+                 dlrm_stream_t stream);
+
 /* ------------------------------------------------------------ EmbeddingBag */
 
 /*

@@ -1,0 +1,94 @@
+"""One DLRM train step assembled from the CPU oracle's operators -- the
+checker for dlrm_amd.model (test infrastructure only)."""
+import numpy as np
+
+
+def oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, n_bottom, lr, feature_order=None,
+                      mean_over=None, emb_opt_state=None):
+    """tables: list (global table order) of [rows, D] float32 arrays, updated in place.
+    Ws/bs: bottom layers then top layers (float32 arrays, updated in place).
+    idx/off: CSR over bags g = t*B + b in GLOBAL table order (include_last_offset).
+    Returns (loss, pred)."""
+    B = dense.shape[0]
+    T, D = len(tables), cfg.dim
+    order = list(range(T)) if feature_order is None else list(feature_order)
+    pooling = orc.POOL_MEAN if cfg.pooling == "mean" else orc.POOL_SUM
+    tro = np.concatenate([[0], np.cumsum([t.shape[0] for t in tables])]).astype(np.int64)
+    w_all = np.concatenate(tables, axis=0)
+    pooled = orc.embbag_forward(w_all, idx, off, B, T, tro, pooling, include_last_offset=True)  # [B, T*D]
+    pooled = pooled.reshape(B, T, D)[:, order, :]
+    # bottom
+    acts = [dense]
+    for i in range(n_bottom):
+        acts.append(orc.linear_forward(acts[-1], Ws[i], bs[i], True))
+    bot = acts[-1]
+    if cfg.interaction == "dot":
+        feat = np.concatenate([bot[:, None, :], pooled], axis=1)
+        inter = orc.interact_dot_forward(feat)
+    else:
+        inter = np.concatenate([bot, pooled.reshape(B, T * D)], axis=1)
+    tacts = [inter]
+    n_top = len(Ws) - n_bottom
+    for i in range(n_top):
+        relu = cfg.final_relu or i + 1 < n_top
+        tacts.append(orc.linear_forward(tacts[-1], Ws[n_bottom + i], bs[n_bottom + i], relu))
+    pred = tacts[-1].reshape(-1)
+    n = mean_over or B
+    if cfg.loss == "bce":
+        loss, dpred = orc.bce_logits_loss(pred, labels)
+    else:
+        loss, dpred = orc.mse_loss(pred, labels)
+    loss *= B / n
+    dpred = (dpred * (B / n)).astype(np.float32)
+    # top backward
+    dy = dpred.reshape(B, 1)
+    dWs, dbs = [None] * len(Ws), [None] * len(Ws)
+    for i in reversed(range(n_top)):
+        relu = cfg.final_relu or i + 1 < n_top
+        dx, dw, db = orc.linear_backward(tacts[i], Ws[n_bottom + i], tacts[i + 1], dy, relu)
+        dWs[n_bottom + i], dbs[n_bottom + i] = dw, db
+        dy = dx
+    dinter = dy
+    if cfg.interaction == "dot":
+        dfeat = orc.interact_dot_backward(feat, dinter)
+        dbot, dpooled = dfeat[:, 0, :], dfeat[:, 1:, :]
+    else:
+        nb = bot.shape[1]
+        dbot, dpooled = dinter[:, :nb], dinter[:, nb:].reshape(B, T, D)
+    # pooled grads back to global table order
+    g = np.empty((B, T, D), dtype=np.float32)
+    g[:, order, :] = dpooled
+    optimizer = orc.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else orc.OPT_SGD
+    orc.embbag_backward_update(w_all, idx, off, B, np.ascontiguousarray(g.reshape(B, T * D)), T, tro, pooling, True,
+                               optimizer, orc.DUP_ACCUMULATE, lr, cfg.eps, emb_opt_state)
+    for t in range(T):
+        tables[t][...] = w_all[tro[t]:tro[t + 1]]
+    dy = np.ascontiguousarray(dbot)
+    for i in reversed(range(n_bottom)):
+        dx, dw, db = orc.linear_backward(acts[i], Ws[i], acts[i + 1], dy, True, need_dx=i > 0)
+        dWs[i], dbs[i] = dw, db
+        dy = dx
+    for i in range(len(Ws)):
+        orc.sgd_step(Ws[i], dWs[i], lr)
+        orc.sgd_step(bs[i], dbs[i], lr)
+    return loss, pred
+
+
+def make_batch(rng, cfg, B, ragged=False):
+    """CSR batch over bags g = t*B + b."""
+    T, L = cfg.num_tables, cfg.lookups
+    if ragged:
+        lens = rng.integers(0, 2 * L + 1, size=T * B)
+    else:
+        lens = np.full(T * B, L)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.empty(int(off[-1]), dtype=np.int64)
+    for t in range(T):
+        s, e = off[t * B], off[(t + 1) * B]
+        idx[s:e] = rng.integers(0, cfg.table_rows[t], size=e - s)
+    dense = rng.standard_normal((B, cfg.dense_in)).astype(np.float32)
+    if cfg.loss == "bce":
+        labels = (rng.random(B) < 0.4).astype(np.float32)
+    else:
+        labels = rng.standard_normal(B).astype(np.float32)
+    return dense, idx, off, labels
