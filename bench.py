@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MLPerf-DLRM-shaped training step, samples/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1: the whole model (26 tables capped at 40M rows, dim 128, ~96 GB fp32) on
+one MI355X, batch 65536.  N > 1 (launched with torch.distributed.run, one rank
+per GPU): the same GLOBAL batch 65536, tables sharded table-wise, pooled
+embeddings exchanged with RCCL all-to-all, MLP gradients all-reduced -- strong
+scaling.  A step = forward, loss, backward, fused sparse row update and dense
+SGD step on synthetic data already resident in HBM.
+
+Rank 0 prints one JSON line (see README/DESIGN for the fields).  `roofline`
+describes the kernel class that takes the most time in the timed region,
+`kernels` lists every class; durations come from HIP events recorded around
+the launches inside the timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12       # B/s, MI355X spec
+F32_MFMA_PEAK = 157.3e12  # FLOP/s, v_mfma_f32_32x32x2_f32 dense peak
+
+
+class KernelTimer:
+    """Wraps dlrm_amd.ops entry points with HIP event pairs on the launch
+    stream and accumulates algorithmic work per kernel class."""
+
+    def __init__(self):
+        self.records = []   # (name, ev0, ev1, work, unit_kind)
+        self.enabled = False
+
+    def wrap(self, ops, name, work_fn, kind):
+        orig = getattr(ops, name)
+        timer = self
+
+        def wrapped(*a, **kw):
+            if not timer.enabled:
+                return orig(*a, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **kw)
+            e1.record()
+            timer.records.append((name, e0, e1, work_fn(*a, **kw), kind))
+            return r
+
+        setattr(ops, name, wrapped)
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, work, kind in self.records:
+            d = out.setdefault(name, {"ms": 0.0, "work": 0.0, "launches": 0, "kind": kind})
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+            d["launches"] += 1
+        return out
+
+
+def install_timers(ops, model_ref):
+    t = KernelTimer()
+
+    def gemm_flops_fwd(x, w, bias, relu, out=None):
+        return 2.0 * x.shape[0] * w.shape[0] * w.shape[1]
+
+    def gemm_flops_bwd_data(dz, w, relu_mask=None, out=None):
+        return 2.0 * dz.shape[0] * w.shape[0] * w.shape[1]
+
+    def gemm_flops_bwd_weight(dz, x, dw=None, db=None, workspace=None, want_db=True):
+        return 2.0 * dz.shape[0] * dz.shape[1] * x.shape[1]
+
+    def emb_fwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, **kw):
+        n_idx, D = indices.numel(), weight.shape[1]
+        return (n_idx * D * weight.element_size() + batch * num_tables * D * 4 +
+                n_idx * indices.element_size() + offsets.numel() * offsets.element_size())
+
+    def emb_bwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, **kw):
+        n_idx, D = indices.numel(), weight.shape[1]
+        U = model_ref["unique_rows"]
+        return batch * num_tables * D * 4 + 2 * U * D * weight.element_size() + n_idx * indices.element_size()
+
+    def inter_fwd_bytes(x, out=None, out_ld=None):
+        B, F, D = x.shape
+        return B * (F * D + D + F * (F - 1) // 2) * 4
+
+    def inter_bwd_bytes(x, dout, relu_mask_feature0=False, out=None):
+        B, F, D = x.shape
+        return B * (2 * F * D + D + F * (F - 1) // 2) * 4
+
+    t.wrap(ops, "linear_forward", gemm_flops_fwd, "mfma")
+    t.wrap(ops, "linear_backward_data", gemm_flops_bwd_data, "mfma")
+    t.wrap(ops, "linear_backward_weight", gemm_flops_bwd_weight, "mfma")
+    t.wrap(ops, "embbag_forward", emb_fwd_bytes, "hbm")
+    t.wrap(ops, "embbag_backward_update", emb_bwd_bytes, "hbm")
+    t.wrap(ops, "interact_dot_forward", inter_fwd_bytes, "hbm")
+    t.wrap(ops, "interact_dot_backward", inter_bwd_bytes, "hbm")
+    return t
+
+
+KERNEL_OF = {
+    "linear_forward": "gemm_f32_kernel<RC,RC> (x W^T + b, ReLU)",
+    "linear_backward_data": "gemm_f32_kernel<RC,RS> (dz W, ReLU mask)",
+    "linear_backward_weight": "gemm_f32_kernel<RS,RS> split-batch + reduce_slabs + colsum (dz^T x)",
+    "embbag_forward": "embbag_fwd_group_kernel",
+    "embbag_backward_update": "expand_pairs + rocprim radix sort + sparse_update_kernel",
+    "interact_dot_forward": "interact_dot_fwd_kernel",
+    "interact_dot_backward": "interact_dot_bwd_kernel",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=65536)
+    ap.add_argument("--config", default="mlperf", choices=["mlperf", "kaggle"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--row-cap", type=int, default=0, help="cap rows per table (debug on small boxes); 0 = none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dlrm_amd import ops
+    from dlrm_amd.data import synthetic_batch
+    from dlrm_amd.model import DLRM, DLRMConfig
+
+    cfg = DLRMConfig.mlperf() if args.config == "mlperf" else DLRMConfig.kaggle()
+    if args.row_cap:
+        cfg.table_rows = [min(r, args.row_cap) for r in cfg.table_rows]
+    Bg = args.global_batch
+    if args.config == "kaggle" and args.global_batch == 65536:
+        Bg = 2048
+    assert Bg % world == 0
+    B = Bg // world
+    model_ref = {"unique_rows": 0}
+    timer = install_timers(ops, model_ref)
+    model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg)
+    local_rows = [cfg.table_rows[t] for t in model.my_tables]
+
+    # a few different batches, resident in HBM, cycled
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):
+        dense, idx, off, labels = synthetic_batch(local_rows, Bg, cfg.lookups, cfg.dense_in, dev,
+                                                  seed=1000 * (i + 1) + rank, loss=cfg.loss, dist=args.dist,
+                                                  local_batch=B)
+        # unique rows touched per batch (for the algorithmic bytes of the sparse update)
+        uniq = 0
+        n_per = Bg * cfg.lookups
+        for lt in range(len(local_rows)):
+            uniq += int(torch.unique(idx[lt * n_per:(lt + 1) * n_per]).numel())
+        batches.append((dense, idx, off, labels, uniq))
+
+    def step(i):
+        dense, idx, off, labels, uniq = batches[i % n_batches]
+        model_ref["unique_rows"] = uniq
+        model.load_batch(dense, labels)
+        return model.train_step(idx, off)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if int(model.err_flag.item()) != 0:
+        raise SystemExit("out-of-range embedding index reported by the kernels")
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt * 1e3 / args.steps
+    value = Bg * args.steps / dt
+
+    # per-kernel-class accounting from the events recorded inside the timed steps
+    summ = timer.summary()
+    kernels = []
+    for name, d in summ.items():
+        sec = d["ms"] * 1e-3
+        ach = d["work"] / sec if sec > 0 else 0.0
+        peak = F32_MFMA_PEAK if d["kind"] == "mfma" else HBM_PEAK
+        kernels.append({
+            "op": name, "kernel": KERNEL_OF.get(name, name), "bound": d["kind"],
+            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s" if d["kind"] == "mfma" else "TB/s",
+            "frac": ach / peak, "ms_per_step": d["ms"] / args.steps, "launches_per_step": d["launches"] / args.steps,
+            "avg_launch_ms": d["ms"] / max(d["launches"], 1),
+        })
+    kernels.sort(key=lambda k: -k["ms_per_step"])
+    dom = kernels[0] if kernels else None
+    roofline = None
+    if dom:
+        roofline = {"kernel": dom["kernel"], "bound": dom["bound"],
+                    "achieved": dom["achieved"] * (1e3 if dom["bound"] == "hbm" else 1.0),
+                    "peak": dom["peak"] * (1e3 if dom["bound"] == "hbm" else 1.0),
+                    "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
+                    "avg_launch_ms": dom["avg_launch_ms"], "traffic": None}
+    emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import time_cpu_baseline
+        cpu_baseline = time_cpu_baseline(cfg, batch=8192, table_rows_cap=200000, warmup=1, steps=5)
+
+    if rank == 0:
+        line = {
+            "metric": "train samples/s (node) MLPerf-DLRM shape @1/2/4/8 GPU; EmbBag HBM GB/s",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (%s ids, random-init weights)" % args.dist,
+            "config": {"workload": cfg.name, "global_batch": Bg, "tables": cfg.num_tables, "dim": cfg.dim,
+                       "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
+                       "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
+                       "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
+                       "parallelism": "single GPU" if world == 1 else "table-wise x%d + data-parallel MLP" % world},
+            "loss": float(loss.item()),
+            "roofline": roofline,
+            "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,
+            "kernels": kernels,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,10 @@ def lib():
                 "libdlrm_amd.so not found at %s: build it with `make -C dlrm_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "There is no CPU fallback." % LIB_PATH)
+        # torch ships its own HIP runtime (same soname as /opt/rocm's).  Import it
+        # first so that libdlrm_amd.so binds to that one runtime: two runtimes in
+        # one process cannot share streams or device memory.
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.dlrm_last_error.restype = C.c_char_p
         _lib.dlrm_target_arch.restype = C.c_char_p

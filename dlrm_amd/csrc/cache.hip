@@ -1,0 +1,697 @@
+// HBM-resident embedding page cache over a pinned host-DRAM backing store.
+//
+// Replaces class cache (dlrm_libtorch/include/data.h:242-298,
+// src/emb_cache.cpp) and the policy driver reclaim_emb_cache
+// (src/dlrmtest.cpp:397-412), with host DRAM standing in for the OCSSD.
+//
+// State (all in HBM): a direct page map (slot of every page of every table, or
+// -1), the slot pool [num_slots][rows_per_page][dim] that the EmbeddingBag
+// kernels read and update in place, per-slot (page, last-use epoch), a ring of
+// free slots and per-table counters.  288 GB of HBM make a direct map cheaper
+// than any hash: 4 bytes per page.
+//
+// Recency is kept per lookup call ("epoch"); inside one call pages count as
+// touched in ascending page order.  That is exactly the order the reference's
+// std::list ends up in, because its driver sorts the ids of a batch before
+// calling get_emb_vectors (src/dlrmtest.cpp:62-63): LRU order == ascending
+// (epoch, page).  So the victims of a reclaim are, per table, the smallest
+// (epoch, page) keys -- found with an age histogram + a sort of the few
+// candidates instead of a linked list walk.
+//
+// Determinism: missed pages are sorted, then take free slots in ring order;
+// evicted slots return to the ring in eviction order (pass-major, table, LRU
+// first).  The page->slot map and every counter are therefore pure functions
+// of the call sequence and can be compared bit for bit with the CPU
+// restatement.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace dlrm {
+
+constexpr int kMaxCacheTables = 64;
+constexpr int kAgeBins = 1024;
+constexpr int kCacheThreads = 256;
+constexpr int kNumCounters = 6;  // read_pages, write_pages, hit_ids, miss_ids, evicted_pages, resident_pages
+enum { C_READ = 0, C_WRITE = 1, C_HIT = 2, C_MISS = 3, C_EVICT = 4, C_RESIDENT = 5 };
+enum { S_HEAD = 0, S_TAIL, S_PAGE_COUNT, S_CACHE_SIZE, S_N_MISS, S_N_CAND, S_ERROR, S_EPOCH, S_PASSES, S_N_ASSIGNED,
+       S_COUNT };
+enum { ERR_BAD_ID = 1, ERR_POOL_EXHAUSTED = 2, ERR_EVICTED_CURRENT = 4 };
+
+struct TableGeom {
+    int T;
+    int vpo;            // rows per page
+    int ws;             // pages evicted per table per pass
+    int dim;
+    int esz;            // bytes per element
+    int64_t page_bytes;
+    int64_t rows[kMaxCacheTables];
+    int64_t page_base[kMaxCacheTables + 1];  // first global page id of each table
+    char *store[kMaxCacheTables];            // pinned host backing store per table (device accessible)
+};
+
+struct IdLayout {
+    int64_t off[kMaxCacheTables + 1];  // ids of table t sit at positions [off[t], off[t+1])
+};
+
+struct CacheDev {
+    int32_t *page_map;
+    int32_t *slot_gp;
+    uint32_t *slot_epoch;
+    int32_t *ring;
+    int64_t *scalars;
+    int64_t *counters;   // [T][kNumCounters]
+    int64_t *k_t;        // [T] victims per table of the current reclaim
+    int32_t *thr_age;    // [T]
+    uint32_t *hist;      // [T][kAgeBins]
+    int32_t *miss, *miss_sorted;
+    uint64_t *cand_key, *cand_key_sorted;
+    int32_t *cand_val, *cand_val_sorted;
+    char *data;
+    int64_t S;
+};
+
+}  // namespace dlrm
+
+struct dlrm_cache {
+    dlrm::TableGeom g;
+    dlrm::CacheDev d;
+    int64_t total_pages;
+    int64_t miss_cap;        // capacity of the miss buffers (ids per lookup call)
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
+    int64_t *h_scalars;      // pinned staging for scalar read-back
+    bool owns_pool;
+};
+
+namespace dlrm {
+
+__device__ inline int table_of_page(const TableGeom &g, int64_t gp) {
+    int lo = 0, hi = g.T;  // page_base[lo] <= gp < page_base[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (gp >= g.page_base[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline int table_of_pos(const IdLayout &l, int T, int64_t i) {
+    int lo = 0, hi = T;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (i >= l.off[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- lookup ----------------------------------------------------------------
+
+// cache::read() miss detection (src/emb_cache.cpp:410-438) + lru_page() touch (:317-352)
+template <typename IDX>
+__global__ __launch_bounds__(kCacheThreads) void probe_kernel(TableGeom g, CacheDev d, IdLayout l, const IDX *ids,
+                                                               int64_t n) {
+    const uint32_t epoch = (uint32_t)d.scalars[S_EPOCH];
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCacheThreads) {
+        const int t = table_of_pos(l, g.T, i);
+        const int64_t id = (int64_t)ids[i];
+        if (id < 0 || id >= g.rows[t]) {
+            atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_BAD_ID);
+            continue;
+        }
+        const int64_t gp = g.page_base[t] + id / g.vpo;
+        const int32_t s = d.page_map[gp];
+        if (s >= 0) {
+            atomicExch(&d.slot_epoch[s], epoch);
+            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_HIT], 1ull);
+        } else {
+            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_MISS], 1ull);
+            if (s == -1 && atomicCAS(&d.page_map[gp], -1, -2) == -1) {
+                const int64_t pos = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_N_MISS], 1ull);
+                d.miss[pos] = (int32_t)gp;
+            }
+        }
+    }
+}
+
+// missed pages (ascending) take free slots in ring order (emb_cache.cpp:502-512 installs the pages)
+__global__ __launch_bounds__(kCacheThreads) void assign_kernel(TableGeom g, CacheDev d) {
+    const int64_t n_miss = d.scalars[S_N_MISS];
+    const int64_t head = d.scalars[S_HEAD], avail = d.scalars[S_TAIL] - head;
+    const uint32_t epoch = (uint32_t)d.scalars[S_EPOCH];
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n_miss;
+         i += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t gp = d.miss_sorted[i];
+        const int t = table_of_page(g, gp);
+        if (i < avail) {
+            const int32_t s = d.ring[(head + i) % d.S];
+            d.page_map[gp] = s;
+            d.slot_gp[s] = (int32_t)gp;
+            d.slot_epoch[s] = epoch;
+            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_READ], 1ull);
+            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_RESIDENT], 1ull);
+        } else {
+            d.page_map[gp] = -1;
+            atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_POOL_EXHAUSTED);
+        }
+    }
+}
+
+// bytes of page gp that hold rows (the last page of a table may be partial)
+__device__ inline int64_t valid_page_bytes(const TableGeom &g, int t, int64_t page) {
+    const int64_t rows_left = g.rows[t] - page * g.vpo;
+    const int64_t r = rows_left < g.vpo ? rows_left : g.vpo;
+    return r * g.dim * g.esz;
+}
+
+// backing store -> slot: the device read replaces nvm_cmd_read + decode (emb_cache.cpp:451-497).
+// One lane moves 16 bytes; a page is covered by consecutive lanes (coalesced on both sides).
+__global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheDev d) {
+    const int64_t n_miss = d.scalars[S_N_MISS];
+    const int64_t avail = d.scalars[S_TAIL] - d.scalars[S_HEAD];
+    const int64_t n = n_miss < avail ? n_miss : avail;
+    const int64_t chunks = g.page_bytes / 16;
+    const int64_t total = n * chunks;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / chunks, c = w - i * chunks;
+        const int64_t gp = d.miss_sorted[i];
+        const int t = table_of_page(g, gp);
+        const int64_t page = gp - g.page_base[t];
+        if (c * 16 < valid_page_bytes(g, t, page)) {
+            const int32_t s = d.page_map[gp];
+            const uint4 v = *reinterpret_cast<const uint4 *>(g.store[t] + page * g.page_bytes + c * 16);
+            *reinterpret_cast<uint4 *>(d.data + (int64_t)s * g.page_bytes + c * 16) = v;
+        }
+    }
+}
+
+// row index of every id inside the slot pool (what get_emb_vectors returns as row pointers, :364-367)
+template <typename IDX>
+__global__ __launch_bounds__(kCacheThreads) void translate_kernel(TableGeom g, CacheDev d, IdLayout l, const IDX *ids,
+                                                                   int64_t n, IDX *rows_out) {
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCacheThreads) {
+        const int t = table_of_pos(l, g.T, i);
+        const int64_t id = (int64_t)ids[i];
+        IDX r = (IDX)-1;
+        if (id >= 0 && id < g.rows[t]) {
+            const int32_t s = d.page_map[g.page_base[t] + id / g.vpo];
+            if (s >= 0) r = (IDX)((int64_t)s * g.vpo + id % g.vpo);
+        }
+        rows_out[i] = r;
+    }
+}
+
+__global__ void begin_lookup_kernel(CacheDev d) {
+    d.scalars[S_EPOCH] += 1;   // every call is one step of recency
+    d.scalars[S_N_MISS] = 0;
+    d.scalars[S_N_ASSIGNED] = 0;
+}
+
+__global__ void reset_rw_counters_kernel(int64_t *cnt, int T) {
+    const int t = threadIdx.x;
+    if (t < T) { cnt[t * kNumCounters + C_READ] = 0; cnt[t * kNumCounters + C_WRITE] = 0; }
+}
+
+__global__ void finish_lookup_kernel(CacheDev d) {
+    const int64_t n_miss = d.scalars[S_N_MISS];
+    const int64_t avail = d.scalars[S_TAIL] - d.scalars[S_HEAD];
+    const int64_t n = n_miss < avail ? n_miss : avail;
+    d.scalars[S_HEAD] += n;
+    d.scalars[S_PAGE_COUNT] += n;   // page_count += lookup (emb_cache.cpp:441)
+    d.scalars[S_N_ASSIGNED] = n;
+    d.scalars[S_N_MISS] = 0;
+}
+
+// ---- reclaim ---------------------------------------------------------------
+
+// reclaim_emb_cache (src/dlrmtest.cpp:397-403): while (page_count > cache_size) one
+// Reclaim_vector_page per table; each drops ws pages (emb_cache.cpp:223-238, :312)
+__global__ void plan_reclaim_kernel(TableGeom g, CacheDev d) {
+    const int64_t pc = d.scalars[S_PAGE_COUNT], cs = d.scalars[S_CACHE_SIZE];
+    const int64_t per_pass = (int64_t)g.T * g.ws;
+    const int64_t passes = pc > cs ? (pc - cs + per_pass - 1) / per_pass : 0;
+    d.scalars[S_PASSES] = passes;
+    d.scalars[S_N_CAND] = 0;
+    for (int t = 0; t < g.T; t++) {
+        const int64_t res = d.counters[t * kNumCounters + C_RESIDENT];
+        const int64_t want = passes * g.ws;
+        d.k_t[t] = want < res ? want : res;
+    }
+}
+
+__global__ __launch_bounds__(kCacheThreads) void age_hist_kernel(TableGeom g, CacheDev d) {
+    if (d.scalars[S_PASSES] == 0) return;
+    const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
+    for (int64_t s = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; s < d.S; s += (int64_t)gridDim.x * kCacheThreads) {
+        const int32_t gp = d.slot_gp[s];
+        if (gp < 0) continue;
+        const int t = table_of_page(g, gp);
+        uint32_t age = now - d.slot_epoch[s];
+        if (age > kAgeBins - 1) age = kAgeBins - 1;
+        atomicAdd(&d.hist[t * kAgeBins + age], 1u);
+    }
+}
+
+// per table: the youngest age a* such that the pages of age >= a* number at least k_t
+__global__ void threshold_kernel(TableGeom g, CacheDev d) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.T) return;
+    int thr = kAgeBins;  // nothing to evict
+    const int64_t k = d.scalars[S_PASSES] == 0 ? 0 : d.k_t[t];
+    if (k > 0) {
+        int64_t cum = 0;
+        for (int a = kAgeBins - 1; a >= 0; a--) {
+            cum += d.hist[t * kAgeBins + a];
+            if (cum >= k) { thr = a; break; }
+        }
+        if (thr == kAgeBins) thr = 0;
+    }
+    d.thr_age[t] = thr;
+    for (int a = 0; a < kAgeBins; a++) d.hist[t * kAgeBins + a] = 0;
+}
+
+__global__ __launch_bounds__(kCacheThreads) void collect_candidates_kernel(TableGeom g, CacheDev d) {
+    if (d.scalars[S_PASSES] == 0) return;
+    const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
+    for (int64_t s = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; s < d.S; s += (int64_t)gridDim.x * kCacheThreads) {
+        const int32_t gp = d.slot_gp[s];
+        if (gp < 0) continue;
+        const int t = table_of_page(g, gp);
+        uint32_t age = now - d.slot_epoch[s];
+        if (age > kAgeBins - 1) age = kAgeBins - 1;
+        if ((int)age >= d.thr_age[t]) {
+            const int64_t pos = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_N_CAND], 1ull);
+            d.cand_key[pos] = ((uint64_t)t << 58) | ((uint64_t)(d.slot_epoch[s] & 0x3ffffffu) << 32) | (uint32_t)gp;
+            d.cand_val[pos] = (int32_t)s;
+        }
+    }
+}
+
+// rank of candidate i inside its table (candidates are sorted by table, epoch, page)
+__device__ inline int64_t cand_rank(const uint64_t *keys, int64_t n, int64_t i, int t) {
+    const uint64_t first_key = (uint64_t)t << 58;
+    int64_t lo = 0, hi = i;  // lower bound of first_key in [0, i]
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < first_key) lo = mid + 1; else hi = mid;
+    }
+    return i - lo;
+}
+
+// Position of every candidate in eviction order (pass-major, then table, then LRU rank inside the
+// pass), or -1 when it survives: candidate i of table t is a victim iff its rank r < k_t.
+__global__ __launch_bounds__(kCacheThreads) void rank_victims_kernel(TableGeom g, CacheDev d, int64_t n_cand,
+                                                                      int32_t *cand_pos) {
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n_cand;
+         i += (int64_t)gridDim.x * kCacheThreads) {
+        const uint64_t key = d.cand_key_sorted[i];
+        const int t = (int)(key >> 58);
+        const int64_t r = cand_rank(d.cand_key_sorted, n_cand, i, t);
+        int64_t pos = -1;
+        if (r < d.k_t[t]) {
+            const int64_t p = r / g.ws;
+            pos = r - p * g.ws;
+            for (int u = 0; u < g.T; u++) {
+                const int64_t ku = d.k_t[u];
+                pos += ku < p * g.ws ? ku : p * g.ws;
+                if (u < t) {
+                    int64_t in_pass = ku - p * g.ws;
+                    in_pass = in_pass < 0 ? 0 : (in_pass > g.ws ? g.ws : in_pass);
+                    pos += in_pass;
+                }
+            }
+        }
+        cand_pos[i] = (int32_t)pos;
+    }
+}
+
+// slot -> backing store for every victim: replaces the serialise + nvm_cmd_write of
+// Reclaim_vector_page (emb_cache.cpp:259-272, :305); every evicted page is written (no dirty bit there)
+__global__ __launch_bounds__(kCacheThreads) void writeback_victims_kernel(TableGeom g, CacheDev d, int64_t n_cand,
+                                                                           const int32_t *cand_pos) {
+    const int64_t chunks = g.page_bytes / 16;
+    const int64_t total = n_cand * chunks;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / chunks, c = w - i * chunks;
+        if (cand_pos[i] < 0) continue;
+        const uint64_t key = d.cand_key_sorted[i];
+        const int t = (int)(key >> 58);
+        const int64_t gp = (int64_t)(uint32_t)key;
+        const int64_t page = gp - g.page_base[t];
+        if (c * 16 < valid_page_bytes(g, t, page)) {
+            const int32_t s = d.cand_val_sorted[i];
+            const uint4 v = *reinterpret_cast<const uint4 *>(d.data + (int64_t)s * g.page_bytes + c * 16);
+            *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kCacheThreads) void evict_kernel(TableGeom g, CacheDev d, int64_t n_cand,
+                                                               const int32_t *cand_pos) {
+    const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
+    const int64_t tail = d.scalars[S_TAIL];
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n_cand;
+         i += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t pos = cand_pos[i];
+        if (pos < 0) continue;
+        const uint64_t key = d.cand_key_sorted[i];
+        const int32_t s = d.cand_val_sorted[i];
+        const int64_t gp = (int64_t)(uint32_t)key;
+        // a page used by the current call is being dropped: the caller's row indices into the
+        // slot pool go stale (the reference would crash in save_emb on the freed page)
+        if (d.slot_epoch[s] == now) atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_EVICTED_CURRENT);
+        d.ring[(tail + pos) % d.S] = s;
+        d.page_map[gp] = -1;
+        d.slot_gp[s] = -1;
+    }
+}
+
+__global__ void finish_reclaim_kernel(TableGeom g, CacheDev d) {
+    const int64_t passes = d.scalars[S_PASSES];
+    int64_t freed = 0;
+    for (int t = 0; t < g.T; t++) {
+        const int64_t k = d.k_t[t];
+        freed += k;
+        d.counters[t * kNumCounters + C_EVICT] += k;
+        d.counters[t * kNumCounters + C_RESIDENT] -= k;
+        d.counters[t * kNumCounters + C_WRITE] += passes * g.ws;   // write_page_count += ws_opt per call (:315)
+    }
+    d.scalars[S_TAIL] += freed;
+    d.scalars[S_PAGE_COUNT] -= passes * g.T * g.ws;               // page_count -= ws_opt per call (:312)
+    d.scalars[S_PASSES] = 0;
+}
+
+__global__ __launch_bounds__(kCacheThreads) void flush_kernel(TableGeom g, CacheDev d) {
+    const int64_t chunks = g.page_bytes / 16;
+    const int64_t total = d.S * chunks;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t s = w / chunks, c = w - s * chunks;
+        const int32_t gp = d.slot_gp[s];
+        if (gp < 0) continue;
+        const int t = table_of_page(g, gp);
+        const int64_t page = gp - g.page_base[t];
+        if (c * 16 < valid_page_bytes(g, t, page)) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(d.data + s * g.page_bytes + c * 16);
+            *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) = v;
+        }
+    }
+}
+
+__global__ void init_ring_kernel(CacheDev d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.S; i += (int64_t)gridDim.x * blockDim.x) {
+        d.ring[i] = (int32_t)i;
+        d.slot_gp[i] = -1;
+        d.slot_epoch[i] = 0;
+    }
+}
+
+static unsigned grid_for(int64_t n) {
+    const int64_t b = ceil_div(n > 0 ? n : 1, kCacheThreads);
+    return (unsigned)(b < 4096 ? b : 4096);
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count) {
+    DLRM_HIP(hipMalloc(reinterpret_cast<void **>(p), sizeof(T) * (count ? count : 1)));
+    return DLRM_OK;
+}
+
+static int read_scalars(dlrm_cache *c, hipStream_t s) {
+    DLRM_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, sizeof(int64_t) * S_COUNT, hipMemcpyDeviceToHost, s));
+    DLRM_HIP(hipStreamSynchronize(s));
+    return DLRM_OK;
+}
+
+}  // namespace dlrm
+
+using namespace dlrm;
+
+extern "C" int dlrm_host_alloc(void **h_ptr, size_t bytes) {
+    DLRM_REQUIRE(h_ptr != nullptr, "h_ptr is NULL");
+    DLRM_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_host_free(void *h_ptr) {
+    if (h_ptr) DLRM_HIP(hipHostFree(h_ptr));
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out) {
+    DLRM_REQUIRE(cfg != nullptr && out != nullptr, "NULL argument");
+    DLRM_REQUIRE(cfg->num_tables >= 1 && cfg->num_tables <= kMaxCacheTables, "num_tables must be 1..%d", kMaxCacheTables);
+    DLRM_REQUIRE(cfg->dim >= 1 && cfg->rows_per_page >= 1 && cfg->evict_group >= 1, "bad geometry");
+    DLRM_REQUIRE(cfg->row_dtype == DLRM_F32 || cfg->row_dtype == DLRM_BF16, "row_dtype %d", cfg->row_dtype);
+    DLRM_REQUIRE(cfg->table_rows != nullptr && cfg->h_table_store != nullptr, "table_rows / h_table_store is NULL");
+    DLRM_REQUIRE(cfg->num_slots >= 1 && cfg->num_slots < (1ll << 31), "num_slots out of range");
+    const int esz = cfg->row_dtype == DLRM_F32 ? 4 : 2;
+    const int64_t page_bytes = (int64_t)cfg->rows_per_page * cfg->dim * esz;
+    DLRM_REQUIRE(page_bytes % 16 == 0, "a page (%lld bytes) must be a multiple of 16 bytes", (long long)page_bytes);
+
+    dlrm_cache *c = new dlrm_cache();
+    memset(c, 0, sizeof(*c));
+    TableGeom &g = c->g;
+    g.T = cfg->num_tables; g.vpo = cfg->rows_per_page; g.ws = cfg->evict_group; g.dim = cfg->dim; g.esz = esz;
+    g.page_bytes = page_bytes;
+    g.page_base[0] = 0;
+    for (int t = 0; t < g.T; t++) {
+        if (cfg->table_rows[t] < 1 || cfg->h_table_store[t] == nullptr) {
+            delete c;
+            return set_error(DLRM_ERR_INVALID, "table %d: rows < 1 or NULL backing store", t);
+        }
+        g.rows[t] = cfg->table_rows[t];
+        g.page_base[t + 1] = g.page_base[t] + ceil_div(g.rows[t], g.vpo);
+        // pinned host memory is addressed by the device through its mapped alias
+        void *dptr = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&dptr, cfg->h_table_store[t], 0);
+        if (e != hipSuccess) {
+            delete c;
+            return set_error(DLRM_ERR_HIP, "table %d backing store is not pinned, device-accessible host memory: %s", t,
+                             hipGetErrorString(e));
+        }
+        g.store[t] = static_cast<char *>(dptr);
+    }
+    c->total_pages = g.page_base[g.T];
+    if (c->total_pages >= 0x7f7f7f7fll) {
+        delete c;
+        return set_error(DLRM_ERR_INVALID, "too many pages (%lld) for 32-bit page ids", (long long)c->total_pages);
+    }
+    CacheDev &d = c->d;
+    d.S = cfg->num_slots;
+    int rc = DLRM_OK;
+    if (!rc) rc = dev_alloc(&d.page_map, (size_t)c->total_pages);
+    if (!rc) rc = dev_alloc(&d.slot_gp, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.slot_epoch, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.ring, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.scalars, (size_t)S_COUNT);
+    if (!rc) rc = dev_alloc(&d.counters, (size_t)g.T * kNumCounters);
+    if (!rc) rc = dev_alloc(&d.k_t, (size_t)g.T);
+    if (!rc) rc = dev_alloc(&d.thr_age, (size_t)g.T);
+    if (!rc) rc = dev_alloc(&d.hist, (size_t)g.T * kAgeBins);
+    if (!rc) rc = dev_alloc(&d.cand_key, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.cand_key_sorted, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.cand_val, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.cand_val_sorted, (size_t)d.S);
+    if (cfg->d_slot_pool) {
+        d.data = static_cast<char *>(cfg->d_slot_pool);
+        if (reinterpret_cast<uintptr_t>(d.data) % 16 != 0) rc = set_error(DLRM_ERR_INVALID, "d_slot_pool must be 16-byte aligned");
+    } else {
+        c->owns_pool = true;
+        if (!rc) rc = dev_alloc(&d.data, (size_t)d.S * (size_t)page_bytes);
+    }
+    if (!rc && hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), sizeof(int64_t) * S_COUNT, 0) != hipSuccess)
+        rc = set_error(DLRM_ERR_NOMEM, "hipHostMalloc failed");
+    if (rc) { dlrm_cache_destroy(c); return rc; }
+    (void)hipMemset(d.page_map, 0xff, sizeof(int32_t) * (size_t)c->total_pages);
+    (void)hipMemset(d.scalars, 0, sizeof(int64_t) * S_COUNT);
+    (void)hipMemset(d.counters, 0, sizeof(int64_t) * g.T * kNumCounters);
+    (void)hipMemset(d.hist, 0, sizeof(uint32_t) * g.T * kAgeBins);
+    hipLaunchKernelGGL(init_ring_kernel, dim3(grid_for(d.S)), dim3(256), 0, 0, d);
+    int64_t init[S_COUNT] = {0};
+    init[S_TAIL] = d.S;
+    init[S_CACHE_SIZE] = cfg->cache_size;
+    (void)hipMemcpy(d.scalars, init, sizeof(init), hipMemcpyHostToDevice);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        dlrm_cache_destroy(c);
+        return set_error(DLRM_ERR_HIP, "cache initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *out = c;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_destroy(dlrm_cache *c) {
+    if (!c) return DLRM_OK;
+    CacheDev &d = c->d;
+    (void)hipFree(d.page_map); (void)hipFree(d.slot_gp); (void)hipFree(d.slot_epoch); (void)hipFree(d.ring); (void)hipFree(d.scalars);
+    (void)hipFree(d.counters); (void)hipFree(d.k_t); (void)hipFree(d.thr_age); (void)hipFree(d.hist); (void)hipFree(d.miss); (void)hipFree(d.miss_sorted);
+    (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted); (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
+    if (c->owns_pool) (void)hipFree(d.data);
+    (void)hipFree(c->sort_tmp);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    delete c;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_storage(dlrm_cache *c, void **d_data, int64_t *total_rows) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    if (d_data) *d_data = c->d.data;
+    if (total_rows) *total_rows = c->d.S * c->g.vpo;
+    return DLRM_OK;
+}
+
+static int ensure_lookup_buffers(dlrm_cache *c, int64_t n) {
+    if (n <= c->miss_cap) return DLRM_OK;
+    (void)hipFree(c->d.miss); (void)hipFree(c->d.miss_sorted);
+    c->d.miss = c->d.miss_sorted = nullptr;
+    c->miss_cap = 0;
+    if (int rc = dev_alloc(&c->d.miss, (size_t)n)) return rc;
+    if (int rc = dev_alloc(&c->d.miss_sorted, (size_t)n)) return rc;
+    c->miss_cap = n;
+    return DLRM_OK;
+}
+
+static int ensure_sort_tmp(dlrm_cache *c, size_t bytes) {
+    if (bytes <= c->sort_tmp_bytes) return DLRM_OK;
+    (void)hipFree(c->sort_tmp);
+    c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+    DLRM_HIP(hipMalloc(&c->sort_tmp, bytes));
+    c->sort_tmp_bytes = bytes;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
+                                 void *d_rows_out, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr && h_table_offsets != nullptr, "NULL argument");
+    DLRM_REQUIRE(idx_dtype == DLRM_I32 || idx_dtype == DLRM_I64, "idx_dtype %d", idx_dtype);
+    IdLayout l;
+    for (int t = 0; t <= c->g.T; t++) {
+        l.off[t] = h_table_offsets[t];
+        DLRM_REQUIRE(t == 0 ? l.off[0] == 0 : l.off[t] >= l.off[t - 1], "table offsets must start at 0 and ascend");
+    }
+    const int64_t n = l.off[c->g.T];
+    hipStream_t s = as_stream(stream);
+    if (n == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_ids != nullptr && d_rows_out != nullptr, "d_ids / d_rows_out is NULL");
+    // (buffers grow outside of steady state only; a caller that must not allocate sizes
+    //  its first call to the largest batch)
+    if (int rc = ensure_lookup_buffers(c, n)) return rc;
+    const int bits = 31;  // whole non-negative int32 range: the 0x7f7f7f7f fill of unused entries sorts last
+    size_t tmp = 0;
+    DLRM_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d.miss, c->d.miss_sorted, (size_t)n, 0u, (unsigned)bits, s, false));
+    if (int rc = ensure_sort_tmp(c, tmp)) return rc;
+
+    // a new epoch for this call; unused miss entries sort to the end
+    DLRM_HIP(hipMemsetAsync(c->d.miss, 0x7f, sizeof(int32_t) * (size_t)n, s));
+    hipLaunchKernelGGL(begin_lookup_kernel, dim3(1), dim3(1), 0, s, c->d);
+    if (idx_dtype == DLRM_I64)
+        hipLaunchKernelGGL(probe_kernel<int64_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
+                           static_cast<const int64_t *>(d_ids), n);
+    else
+        hipLaunchKernelGGL(probe_kernel<int32_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
+                           static_cast<const int32_t *>(d_ids), n);
+    DLRM_LAUNCH_CHECK();
+    tmp = c->sort_tmp_bytes;
+    DLRM_HIP(rocprim::radix_sort_keys(c->sort_tmp, tmp, c->d.miss, c->d.miss_sorted, (size_t)n, 0u, (unsigned)bits, s,
+                                      false));
+    hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(kCacheThreads), 0, s, c->g, c->d);
+    if (idx_dtype == DLRM_I64)
+        hipLaunchKernelGGL(translate_kernel<int64_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
+                           static_cast<const int64_t *>(d_ids), n, static_cast<int64_t *>(d_rows_out));
+    else
+        hipLaunchKernelGGL(translate_kernel<int32_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
+                           static_cast<const int32_t *>(d_ids), n, static_cast<int32_t *>(d_rows_out));
+    hipLaunchKernelGGL(finish_lookup_kernel, dim3(1), dim3(1), 0, s, c->d);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(plan_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(age_hist_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(64), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(collect_candidates_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
+    DLRM_LAUNCH_CHECK();
+    // the candidate count decides the size of the sort: one small read-back per reclaim
+    if (int rc = read_scalars(c, s)) return rc;
+    const int64_t passes = c->h_scalars[S_PASSES], n_cand = c->h_scalars[S_N_CAND];
+    if (passes == 0) return DLRM_OK;
+    if (n_cand > 0) {
+        size_t tmp = 0;
+        DLRM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d.cand_key, c->d.cand_key_sorted, c->d.cand_val,
+                                           c->d.cand_val_sorted, (size_t)n_cand, 0u, 64u, s, false));
+        if (int rc = ensure_sort_tmp(c, tmp)) return rc;
+        tmp = c->sort_tmp_bytes;
+        DLRM_HIP(rocprim::radix_sort_pairs(c->sort_tmp, tmp, c->d.cand_key, c->d.cand_key_sorted, c->d.cand_val,
+                                           c->d.cand_val_sorted, (size_t)n_cand, 0u, 64u, s, false));
+        int32_t *cand_pos = c->d.cand_val;  // the unsorted value buffer is free once the sort is done
+        hipLaunchKernelGGL(rank_victims_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
+                           cand_pos);
+        hipLaunchKernelGGL(writeback_victims_kernel, dim3(4096), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
+                           cand_pos);
+        hipLaunchKernelGGL(evict_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
+                           cand_pos);
+    }
+    hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(kCacheThreads), 0, as_stream(stream), c->g, c->d);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_counters(dlrm_cache *c, int64_t *h_out, int32_t reset_read_write, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    hipStream_t s = as_stream(stream);
+    const size_t bytes = sizeof(int64_t) * c->g.T * kNumCounters;
+    DLRM_HIP(hipMemcpyAsync(h_out, c->d.counters, bytes, hipMemcpyDeviceToHost, s));
+    DLRM_HIP(hipStreamSynchronize(s));
+    if (reset_read_write) {
+        // cache::read_page(i) / write_page(i) zero the two page counters after logging (include/data.h:274-285)
+        hipLaunchKernelGGL(reset_rw_counters_kernel, dim3(1), dim3(64), 0, s, c->d.counters, c->g.T);
+        DLRM_LAUNCH_CHECK();
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_state(dlrm_cache *c, dlrm_cache_state_t *h_state, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr && h_state != nullptr, "NULL argument");
+    if (int rc = read_scalars(c, as_stream(stream))) return rc;
+    h_state->page_count = c->h_scalars[S_PAGE_COUNT];
+    h_state->cache_size = c->h_scalars[S_CACHE_SIZE];
+    h_state->ring_head = c->h_scalars[S_HEAD];
+    h_state->ring_tail = c->h_scalars[S_TAIL];
+    h_state->epoch = c->h_scalars[S_EPOCH];
+    h_state->error_flags = c->h_scalars[S_ERROR];
+    h_state->last_lookup_pages_read = c->h_scalars[S_N_ASSIGNED];
+    h_state->total_pages = c->total_pages;
+    h_state->num_slots = c->d.S;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_set_cache_size(dlrm_cache *c, int64_t cache_size, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    hipStream_t s = as_stream(stream);
+    DLRM_HIP(hipMemcpyAsync(c->d.scalars + S_CACHE_SIZE, &cache_size, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    DLRM_HIP(hipStreamSynchronize(s));
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_export_page_map(dlrm_cache *c, int32_t table, int32_t *h_out, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr && h_out != nullptr && table >= 0 && table < c->g.T, "bad argument");
+    hipStream_t s = as_stream(stream);
+    const int64_t n = c->g.page_base[table + 1] - c->g.page_base[table];
+    DLRM_HIP(hipMemcpyAsync(h_out, c->d.page_map + c->g.page_base[table], sizeof(int32_t) * (size_t)n,
+                            hipMemcpyDeviceToHost, s));
+    DLRM_HIP(hipStreamSynchronize(s));
+    return DLRM_OK;
+}

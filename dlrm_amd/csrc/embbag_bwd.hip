@@ -32,6 +32,7 @@ struct WsLayout {
     int32_t *vals_in, *vals_out;
     void *sort_tmp;
     size_t sort_tmp_bytes;
+    float *partial;   // [2 * ceil(n / kSegLen)][dpad] partial row gradients of runs cut at segment boundaries
     size_t total;
 };
 
@@ -43,8 +44,10 @@ static inline int key_bits(int64_t total_rows) {
     return b;
 }
 
+static inline int pad_dim(int dim) { return (dim + 3) / 4 * 4; }
+
 template <typename KEY>
-static int ws_layout(int64_t n, int bits, void *base, WsLayout<KEY> *L) {
+static int ws_layout(int64_t n, int bits, int dim, void *base, WsLayout<KEY> *L) {
     size_t tmp = 0;
     hipError_t err = rocprim::radix_sort_pairs(nullptr, tmp, (KEY *)nullptr, (KEY *)nullptr, (int32_t *)nullptr,
                                                (int32_t *)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t)0,
@@ -58,6 +61,8 @@ static int ws_layout(int64_t n, int bits, void *base, WsLayout<KEY> *L) {
     L->vals_out = reinterpret_cast<int32_t *>(p + o); o += align_up(sizeof(int32_t) * (size_t)n);
     L->sort_tmp = p + o; o += align_up(tmp);
     L->sort_tmp_bytes = tmp;
+    L->partial = reinterpret_cast<float *>(p + o);
+    o += align_up(sizeof(float) * 2 * (size_t)((n + 127) / 128) * (size_t)pad_dim(dim));
     L->total = o;
     return DLRM_OK;
 }
@@ -180,66 +185,35 @@ __device__ inline void load_grad(const float *g, float (&v)[NF]) {
     }
 }
 
-template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
-__global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
-                                                                     const int32_t *__restrict__ vals) {
+// Runs of equal keys are cut at multiples of kSegLen sorted positions, so no group ever sums
+// more than kSegLen gradient rows: a table of 3 rows hit by a 65536-sample batch is 20000-long
+// runs, which one group would otherwise walk alone.
+constexpr int kSegLen = 128;
+
+template <int NF>
+__device__ inline void load_vec(const float *g, float (&v)[NF]) { load_grad<NF>(g, v); }
+
+template <int NF>
+__device__ inline void store_vec(float *g, const float (&v)[NF]) {
+    if constexpr (NF == 1) {
+        g[0] = v[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NF; q += 4) *reinterpret_cast<float4 *>(g + q) = make_float4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+    }
+}
+
+// optimizer step on row k with the summed gradient acc (each touched row is read and written once)
+template <typename ROW, int VEC16, int G, int NC>
+__device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
+                                        const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
-    constexpr int GROUPS = kBwdThreads / G;
-    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
-    const int64_t i = (int64_t)blockIdx.x * GROUPS + grp;
-    if (i >= p.n_idx) return;
-    const KEY k = keys[i];
-    if ((int64_t)k >= p.total_rows) return;      // out-of-range index, reported by the expand kernel
-    if (i > 0 && keys[i - 1] == k) return;       // not the first occurrence of this row
-    const IDX *off = static_cast<const IDX *>(p.off);
-
-    int col[NC];
-    bool col_ok[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        col[c] = (c * G + lig) * NF;
-        col_ok[c] = col[c] < p.D;
-    }
-    float acc[NC][NF];
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-#pragma unroll
-        for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
-
-    // the row itself can be fetched while the gradients are being summed
     float w[NC][NF];
-    const int64_t e0 = (int64_t)k * p.D;
+    const int64_t e0 = k * p.D;
 #pragma unroll
     for (int c = 0; c < NC; c++)
         if (col_ok[c]) RW::load(p.w, e0 + col[c], w[c]);
-
-    int64_t j = i;
-    if (p.last_wins)
-        while (j + 1 < p.n_idx && keys[j + 1] == k) j++;
-    for (;;) {
-        const uint32_t g = (uint32_t)vals[j];
-        const uint32_t t = g / (uint32_t)p.B;
-        const uint32_t b = g - t * (uint32_t)p.B;
-        float sc = 1.0f;
-        if (p.mean) {
-            const int64_t s = (int64_t)off[g];
-            const int64_t e = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
-            sc = 1.0f / (float)(e - s);
-        }
-        const float *gp = p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (col_ok[c]) {
-                float v[NF];
-                load_grad<NF>(gp + col[c], v);
-#pragma unroll
-                for (int q = 0; q < NF; q++) acc[c][q] += v[q] * sc;
-            }
-        j++;
-        if (j >= p.n_idx || keys[j] != k) break;
-    }
-
     float mult = p.lr;
     if (p.adagrad) {
         float ss = 0.f;
@@ -264,30 +238,162 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
         }
 }
 
+// One G-lane group per sorted position; the group on the first position of a segment (run start or
+// multiple of kSegLen) sums the segment.  A segment that is a whole run is applied at once; pieces
+// of longer runs go to `partial` (2 slots per kSegLen positions: [0] the piece that starts on the
+// boundary, [1] the piece that ends on it) and are combined by combine_runs_kernel.
 template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
-static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, hipStream_t s) {
+__global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
+                                                                     const int32_t *__restrict__ vals,
+                                                                     float *__restrict__ partial, int dpad) {
+    using RW = RowRW<ROW, VEC16>;
+    constexpr int NF = RW::NF;
+    constexpr int GROUPS = kBwdThreads / G;
+    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
+    const int64_t i = (int64_t)blockIdx.x * GROUPS + grp;
+    if (i >= p.n_idx) return;
+    const KEY k = keys[i];
+    if ((int64_t)k >= p.total_rows) return;      // out-of-range index, reported by the expand kernel
+    const bool run_start = i == 0 || keys[i - 1] != k;
+    const IDX *off = static_cast<const IDX *>(p.off);
+    int64_t j, seg_end;
+    if (p.last_wins) {
+        // the reference's write-back keeps only the last occurrence (src/dlrmtest.cpp:96-101)
+        if (i + 1 < p.n_idx && keys[i + 1] == k) return;
+        j = i;
+        seg_end = i + 1;
+    } else {
+        if (!run_start && (i % kSegLen) != 0) return;
+        j = i;
+        seg_end = (i / kSegLen + 1) * kSegLen;
+        if (seg_end > p.n_idx) seg_end = p.n_idx;
+    }
+
+    int col[NC];
+    bool col_ok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        col[c] = (c * G + lig) * NF;
+        col_ok[c] = col[c] < p.D;
+    }
+    float acc[NC][NF];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
+
+    for (;;) {
+        const uint32_t g = (uint32_t)vals[j];
+        const uint32_t t = g / (uint32_t)p.B;
+        const uint32_t b = g - t * (uint32_t)p.B;
+        float sc = 1.0f;
+        if (p.mean) {
+            const int64_t s = (int64_t)off[g];
+            const int64_t e = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
+            sc = 1.0f / (float)(e - s);
+        }
+        const float *gp = p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) {
+                float v[NF];
+                load_grad<NF>(gp + col[c], v);
+#pragma unroll
+                for (int q = 0; q < NF; q++) acc[c][q] += v[q] * sc;
+            }
+        j++;
+        if (j >= seg_end || keys[j] != k) break;
+    }
+    const bool run_end = p.last_wins || j >= p.n_idx || keys[j] != k;
+    if ((run_start || p.last_wins) && run_end) {
+        apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
+    } else {
+        float *dst = partial + (2 * (i / kSegLen) + ((i % kSegLen) == 0 ? 0 : 1)) * (int64_t)dpad;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) store_vec<NF>(dst + col[c], acc[c]);
+    }
+}
+
+// One group per kSegLen positions: if a run starts inside this stretch and goes on beyond it, sum
+// its pieces in position order and apply the update.
+template <typename KEY, typename ROW, int VEC16, int G, int NC>
+__global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, const KEY *__restrict__ keys,
+                                                                    const float *__restrict__ partial, int dpad) {
+    using RW = RowRW<ROW, VEC16>;
+    constexpr int NF = RW::NF;
+    constexpr int GROUPS = kBwdThreads / G;
+    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
+    const int64_t c0 = (int64_t)blockIdx.x * GROUPS + grp;
+    const int64_t s0 = c0 * kSegLen;
+    if (s0 >= p.n_idx) return;
+    const int64_t e = min(p.n_idx, s0 + kSegLen) - 1;
+    if (e + 1 >= p.n_idx) return;
+    const KEY k = keys[e];
+    if ((int64_t)k >= p.total_rows || keys[e + 1] != k) return;   // nothing continues past this stretch
+    const bool whole = keys[s0] == k;                              // the run covers the stretch from its first position
+    if (whole && s0 > 0 && keys[s0 - 1] == k) return;              // the run started earlier: not ours
+
+    int col[NC];
+    bool col_ok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        col[c] = (c * G + lig) * NF;
+        col_ok[c] = col[c] < p.D;
+    }
+    float acc[NC][NF];
+    const float *src = partial + (2 * c0 + (whole ? 0 : 1)) * (int64_t)dpad;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
+        if (col_ok[c]) load_vec<NF>(src + col[c], acc[c]);
+    }
+    for (int64_t cc = c0 + 1; cc * kSegLen < p.n_idx && keys[cc * kSegLen] == k; cc++) {
+        const float *pp = partial + 2 * cc * (int64_t)dpad;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) {
+                float v[NF];
+                load_vec<NF>(pp + col[c], v);
+#pragma unroll
+                for (int q = 0; q < NF; q++) acc[c][q] += v[q];
+            }
+    }
+    apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
+}
+
+template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
+static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, float *partial, int dpad,
+                         hipStream_t s) {
     const int64_t blocks = ceil_div(p.n_idx, kBwdThreads / G);
     hipLaunchKernelGGL((sparse_update_kernel<IDX, KEY, ROW, VEC16, G, NC>), dim3((unsigned)blocks),
-                       dim3(kBwdThreads), 0, s, p, keys, vals);
+                       dim3(kBwdThreads), 0, s, p, keys, vals, partial, dpad);
     DLRM_LAUNCH_CHECK();
+    if (!p.last_wins && p.n_idx > kSegLen) {
+        const int64_t segs = ceil_div(p.n_idx, kSegLen);
+        hipLaunchKernelGGL((combine_runs_kernel<KEY, ROW, VEC16, G, NC>), dim3((unsigned)ceil_div(segs, kBwdThreads / G)),
+                           dim3(kBwdThreads), 0, s, p, keys, partial, dpad);
+        DLRM_LAUNCH_CHECK();
+    }
     return DLRM_OK;
 }
 
 template <typename IDX, typename KEY, typename ROW>
-static int dispatch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, bool vec16, int lanes,
-                           hipStream_t s) {
+static int dispatch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, float *partial, int dpad,
+                           bool vec16, int lanes, hipStream_t s) {
     if (!vec16) {
-        if (lanes <= 64) return launch_update<IDX, KEY, ROW, 0, 64, 1>(p, keys, vals, s);
-        if (lanes <= 128) return launch_update<IDX, KEY, ROW, 0, 64, 2>(p, keys, vals, s);
-        return launch_update<IDX, KEY, ROW, 0, 64, 4>(p, keys, vals, s);
+        if (lanes <= 64) return launch_update<IDX, KEY, ROW, 0, 64, 1>(p, keys, vals, partial, dpad, s);
+        if (lanes <= 128) return launch_update<IDX, KEY, ROW, 0, 64, 2>(p, keys, vals, partial, dpad, s);
+        return launch_update<IDX, KEY, ROW, 0, 64, 4>(p, keys, vals, partial, dpad, s);
     }
-    if (lanes <= 4) return launch_update<IDX, KEY, ROW, 1, 4, 1>(p, keys, vals, s);
-    if (lanes <= 8) return launch_update<IDX, KEY, ROW, 1, 8, 1>(p, keys, vals, s);
-    if (lanes <= 16) return launch_update<IDX, KEY, ROW, 1, 16, 1>(p, keys, vals, s);
-    if (lanes <= 32) return launch_update<IDX, KEY, ROW, 1, 32, 1>(p, keys, vals, s);
-    if (lanes <= 64) return launch_update<IDX, KEY, ROW, 1, 64, 1>(p, keys, vals, s);
-    if (lanes <= 128) return launch_update<IDX, KEY, ROW, 1, 64, 2>(p, keys, vals, s);
-    return launch_update<IDX, KEY, ROW, 1, 64, 4>(p, keys, vals, s);
+    if (lanes <= 4) return launch_update<IDX, KEY, ROW, 1, 4, 1>(p, keys, vals, partial, dpad, s);
+    if (lanes <= 8) return launch_update<IDX, KEY, ROW, 1, 8, 1>(p, keys, vals, partial, dpad, s);
+    if (lanes <= 16) return launch_update<IDX, KEY, ROW, 1, 16, 1>(p, keys, vals, partial, dpad, s);
+    if (lanes <= 32) return launch_update<IDX, KEY, ROW, 1, 32, 1>(p, keys, vals, partial, dpad, s);
+    if (lanes <= 64) return launch_update<IDX, KEY, ROW, 1, 64, 1>(p, keys, vals, partial, dpad, s);
+    if (lanes <= 128) return launch_update<IDX, KEY, ROW, 1, 64, 2>(p, keys, vals, partial, dpad, s);
+    return launch_update<IDX, KEY, ROW, 1, 64, 4>(p, keys, vals, partial, dpad, s);
 }
 
 template <typename IDX, typename KEY>
@@ -295,7 +401,7 @@ static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_
                         hipStream_t s) {
     WsLayout<KEY> L;
     const int bits = key_bits(e->total_rows);
-    if (int rc = ws_layout<KEY>(e->n_indices, bits, ws, &L)) return rc;
+    if (int rc = ws_layout<KEY>(e->n_indices, bits, e->dim, ws, &L)) return rc;
     DLRM_REQUIRE(ws_bytes >= L.total, "workspace too small: %zu < %zu bytes", ws_bytes, L.total);
 
     const double avg_len = (double)e->n_indices / (double)p.n_bags;
@@ -309,8 +415,8 @@ static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_
     DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
                                        (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
     if (e->row_dtype == DLRM_BF16)
-        return dispatch_update<IDX, KEY, uint16_t>(p, L.keys_out, L.vals_out, vec16, lanes, s);
-    return dispatch_update<IDX, KEY, float>(p, L.keys_out, L.vals_out, vec16, lanes, s);
+        return dispatch_update<IDX, KEY, uint16_t>(p, L.keys_out, L.vals_out, L.partial, pad_dim(e->dim), vec16, lanes, s);
+    return dispatch_update<IDX, KEY, float>(p, L.keys_out, L.vals_out, L.partial, pad_dim(e->dim), vec16, lanes, s);
 }
 
 }  // namespace dlrm
@@ -324,11 +430,11 @@ extern "C" int dlrm_embbag_backward_workspace_bytes(const dlrm_embbag *e, size_t
     const int64_t n = e->n_indices > 0 ? e->n_indices : 1;
     if (bits <= 32) {
         WsLayout<uint32_t> L;
-        if (int rc = ws_layout<uint32_t>(n, bits, nullptr, &L)) return rc;
+        if (int rc = ws_layout<uint32_t>(n, bits, e->dim, nullptr, &L)) return rc;
         *bytes = L.total;
     } else {
         WsLayout<uint64_t> L;
-        if (int rc = ws_layout<uint64_t>(n, bits, nullptr, &L)) return rc;
+        if (int rc = ws_layout<uint64_t>(n, bits, e->dim, nullptr, &L)) return rc;
         *bytes = L.total;
     }
     return DLRM_OK;

@@ -54,10 +54,24 @@ struct GemmParams {
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
 // RC: tile rows are output indices, 32 reduction elements (128 B) each: 8 lanes per row.
 // RS: tile rows are reduction indices, 128 output elements (512 B) each: 32 lanes per row.
+// `fast` (uniform over the workgroup): the whole 128 x 32 tile is in range and rows are 16-byte
+// aligned -- four unconditional 16-byte loads with no control flow around them, so all of them
+// are in flight together.  Otherwise every element is guarded (edge tiles, reduction tails,
+// unaligned operands).
 template <bool RC>
 __device__ inline void load_tile(const float *__restrict__ base, int64_t ld, int o0, int o_end, int r0, int r_end,
-                                 bool vec, float4 (&reg)[4]) {
+                                 bool fast, float4 (&reg)[4]) {
     const int tid = threadIdx.x;
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float *p;
+            if constexpr (RC) p = base + (int64_t)(o0 + (tid >> 3) + 32 * u) * ld + r0 + (tid & 7) * 4;
+            else p = base + (int64_t)(r0 + (tid >> 5) + 8 * u) * ld + o0 + (tid & 31) * 4;
+            reg[u] = *reinterpret_cast<const float4 *>(p);
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         int o, r;
@@ -67,24 +81,18 @@ __device__ inline void load_tile(const float *__restrict__ base, int64_t ld, int
         if constexpr (RC) {
             if (o < o_end) {
                 const float *p = base + (int64_t)o * ld + r;
-                if (vec && r + 3 < r_end) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (r < r_end) v.x = p[0];
-                    if (r + 1 < r_end) v.y = p[1];
-                    if (r + 2 < r_end) v.z = p[2];
-                    if (r + 3 < r_end) v.w = p[3];
-                }
+                if (r < r_end) v.x = p[0];
+                if (r + 1 < r_end) v.y = p[1];
+                if (r + 2 < r_end) v.z = p[2];
+                if (r + 3 < r_end) v.w = p[3];
             }
         } else {
             if (r < r_end) {
                 const float *p = base + (int64_t)r * ld + o;
-                if (vec && o + 3 < o_end) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (o < o_end) v.x = p[0];
-                    if (o + 1 < o_end) v.y = p[1];
-                    if (o + 2 < o_end) v.z = p[2];
-                    if (o + 3 < o_end) v.w = p[3];
-                }
+                if (o < o_end) v.x = p[0];
+                if (o + 1 < o_end) v.y = p[1];
+                if (o + 2 < o_end) v.z = p[2];
+                if (o + 3 < o_end) v.w = p[3];
             }
         }
         reg[u] = v;
@@ -138,10 +146,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
+    // tiles whose 128 output indices are all in range can use the unguarded loads
+    const bool a_full = p.a_vec && m0 + BM <= p.M, b_full = p.b_vec && n0 + BN <= p.N;
     float4 ra[4], rb[4];
     if (steps > 0) {
-        load_tile<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, p.a_vec, ra);
-        load_tile<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, p.b_vec, rb);
+        const bool kf = k_begin + BK <= k_end;
+        load_tile<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, a_full && kf, ra);
+        load_tile<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, b_full && kf, rb);
         store_tile<A_RC>(smem[0][0], ra);
         store_tile<B_RC>(smem[0][1], rb);
     }
@@ -152,8 +163,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
         const bool more = st + 1 < steps;
         if (more) {
             const int r0 = k_begin + (st + 1) * BK;
-            load_tile<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, p.a_vec, ra);
-            load_tile<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, p.b_vec, rb);
+            const bool kf = r0 + BK <= k_end;
+            load_tile<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, a_full && kf, ra);
+            load_tile<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, b_full && kf, rb);
         }
         const float *sa = smem[cur][0], *sb = smem[cur][1];
 #pragma unroll

@@ -240,6 +240,95 @@ int dlrm_loss_mse(const float *d_pred, const float *d_target, int64_t n, int64_t
 int dlrm_loss_bce_logits(const float *d_logit, const float *d_target, int64_t n, int64_t mean_over,
                          float *d_loss, float *d_dlogit, dlrm_stream_t stream);
 
+/* ------------------------------------------------------- embedding cache */
+
+/*
+ * HBM-resident page cache in front of a pinned host-DRAM backing store.
+ * Replaces class cache (include/data.h:242-298, src/emb_cache.cpp) and the
+ * policy driver reclaim_emb_cache (src/dlrmtest.cpp:397-412); host DRAM stands
+ * in for the OCSSD.  A page is rows_per_page consecutive rows of one table
+ * (the reference: 4096 / (dim*4) rows, include/data.h:211; 1 gives a row
+ * granular hot-row cache).  Resident pages live in num_slots fixed slots of
+ * one HBM allocation which the EmbeddingBag entry points use as their weight
+ * matrix; dlrm_cache_lookup returns, for every id, its row inside that matrix.
+ *
+ * Replacement is the reference's: per-table LRU, recency advanced once per
+ * lookup call with pages of one call ordered by ascending page id (the
+ * reference driver sorts ids before get_emb_vectors, src/dlrmtest.cpp:62-63,
+ * which gives its std::list exactly this order).  All counters and the
+ * page -> slot map are exact and reproducible (see dlrm_cache_counters).
+ */
+typedef struct dlrm_cache dlrm_cache;
+
+typedef struct dlrm_cache_config {
+    int32_t num_tables;          /* <= 64 */
+    int32_t dim;
+    int32_t row_dtype;           /* DLRM_F32 | DLRM_BF16 */
+    int32_t rows_per_page;       /* cache::vector_page_offset */
+    int32_t evict_group;         /* pages dropped per table per reclaim pass: nvm_dev_get_ws_opt() (8 on the */
+                                 /* reference's device; src/emb_cache.cpp:220) */
+    const int64_t *table_rows;   /* host int64[T] */
+    void *const *h_table_store;  /* host array[T]: pinned, device-accessible [rows_t, dim] row-major store of */
+                                 /* each table (dlrm_host_alloc or hipHostMalloc/hipHostRegister memory) */
+    int64_t num_slots;           /* page slots in HBM: capacity + headroom for the pages one call can read */
+    int64_t cache_size;          /* cache::cache_size: reclaim brings page_count down to at most this */
+    void *d_slot_pool;           /* optional caller-owned HBM for the slots, num_slots*rows_per_page*dim */
+                                 /* elements, 16-byte aligned; NULL = the cache allocates it */
+} dlrm_cache_config;
+
+typedef struct dlrm_cache_state_t {
+    int64_t page_count;             /* cache::page_count (reference arithmetic, include/data.h:289) */
+    int64_t cache_size;
+    int64_t ring_head, ring_tail;   /* free-slot ring cursors (monotonic) */
+    int64_t epoch;                  /* lookup calls so far */
+    int64_t error_flags;            /* 1 id out of range, 2 slot pool exhausted, 4 page of the current call evicted */
+    int64_t last_lookup_pages_read; /* pages the last lookup read from the store */
+    int64_t total_pages, num_slots;
+} dlrm_cache_state_t;
+
+/* Pinned, device-mapped host memory for backing stores (hipHostMalloc). */
+int dlrm_host_alloc(void **h_ptr, size_t bytes);
+int dlrm_host_free(void *h_ptr);
+
+/* cache::cache(table_num, size, dimention) (include/data.h:250).  Allocates device memory; synchronises. */
+int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out);
+int dlrm_cache_destroy(dlrm_cache *c);
+/* The slot pool as an embedding matrix: [num_slots*rows_per_page, dim] (replaces cache::get_vec(), :268). */
+int dlrm_cache_storage(dlrm_cache *c, void **d_data, int64_t *total_rows);
+/*
+ * cache::get_emb_vectors for all tables of a batch (include/data.h:247,
+ * src/emb_cache.cpp:358-371): ids of table t are d_ids[h_table_offsets[t] ..
+ * h_table_offsets[t+1]).  Missing pages are read from the store into free
+ * slots (unique pages, ascending), every referenced page becomes most
+ * recently used, and d_rows_out[i] (same dtype as the ids) is the row of id i
+ * in the slot pool (-1 for an id out of range).  Equals the reference when
+ * ids are sorted per table, as its driver passes them.
+ */
+int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
+                      void *d_rows_out, dlrm_stream_t stream);
+/*
+ * reclaim_emb_cache (src/dlrmtest.cpp:397-403): while page_count > cache_size,
+ * every table drops its evict_group least recently used pages
+ * (cache::Reclaim_vector_page, include/data.h:267); dropped pages are written
+ * back to the store.  Reads one small scalar block back (synchronises).
+ */
+int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream);
+/* Write every resident page back to the store without dropping it. */
+int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream);
+/*
+ * h_out[t*6 + k], k = 0 pages read (write_buffer::read_page_count), 1 pages
+ * written (write_page_count, advances by evict_group per table per pass as in
+ * src/emb_cache.cpp:315), 2 ids that hit, 3 ids that missed, 4 pages evicted,
+ * 5 pages resident.  reset_read_write zeroes k = 0,1 afterwards
+ * (cache::read_page / write_page, include/data.h:274-285).  Synchronises.
+ */
+int dlrm_cache_counters(dlrm_cache *c, int64_t *h_out, int32_t reset_read_write, dlrm_stream_t stream);
+int dlrm_cache_state(dlrm_cache *c, dlrm_cache_state_t *h_state, dlrm_stream_t stream);
+/* cache_size = v (the reference freezes it to page_count, src/dlrmtest.cpp:496-498). */
+int dlrm_cache_set_cache_size(dlrm_cache *c, int64_t cache_size, dlrm_stream_t stream);
+/* Slot of every page of one table (-1 = not resident) into host int32[pages of the table]. Synchronises. */
+int dlrm_cache_export_page_map(dlrm_cache *c, int32_t table, int32_t *h_out, dlrm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+"""HBM page cache vs the CPU restatement of the reference's cache state
+machine: page->slot maps, page_count, and the read / write / hit / miss
+counters must be bit-exact after every call; evicted and flushed pages must
+carry their updated rows back to the store.  Also replays the reference's RMC1
+run and compares per-batch page traffic with the reference's own CSV."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.refdata import reference_batches, reference_dataset
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_lru_base_totals.json")))
+
+
+def sorted_batch(rng, rows_list, n_per_table):
+    ids, offs = [], [0]
+    for r, n in zip(rows_list, n_per_table):
+        ids.append(np.sort(rng.integers(0, r, size=n)))
+        offs.append(offs[-1] + n)
+    return np.concatenate(ids).astype(np.int64), offs
+
+
+def compare_state(cache, pc, T):
+    st = cache.state()
+    assert st.error_flags == 0
+    assert st.page_count == pc.page_count
+    assert st.ring_head == pc.L.orc_pagecache_ring_head(pc.h) and st.ring_tail == pc.L.orc_pagecache_ring_tail(pc.h)
+    cnt = cache.counters()
+    for name in ("read", "write", "hit", "miss"):
+        assert np.array_equal(cnt[name], pc.counters(name)), name
+    for t in range(T):
+        assert np.array_equal(cache.page_map(t).astype(np.int64), pc.slot_map(t)), "slot map of table %d" % t
+
+
+@pytest.mark.parametrize("dim,vpo,idx_t", [(32, None, torch.int64), (128, 1, torch.int32), (16, 4, torch.int64)])
+def test_cache_matches_oracle_state_machine(oracle, dim, vpo, idx_t):
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(dim)
+    rows = [1000, 37, 5000, 64]          # unequal tables; the oracle takes one size: pad to the largest
+    T = len(rows)
+    n_slots, cap, ws = 700, 300, 8
+    cache = EmbeddingCache(rows, dim, cache_size=cap, num_slots=n_slots, rows_per_page=vpo, evict_group=ws)
+    cache.write(seed=3)
+    page_bytes = cache.vpo * dim * 4
+    pc = oracle.PageCache(T, max(rows), dim, cache_size=cap, page_bytes=page_bytes, ws_opt=ws, n_slots=n_slots)
+    assert pc.vpo == cache.vpo
+    expect = [s.copy() for s in cache.store]          # numpy model of every table's current contents
+    for step in range(12):
+        n_per = [int(x) for x in rng.integers(1, 120, size=T)]
+        ids, offs = sorted_batch(rng, rows, n_per)
+        d_ids = torch.from_numpy(ids).to(idx_t).cuda()
+        got_rows = cache.get_emb_vectors(d_ids, offs)
+        for t in range(T):
+            pc.get(t, ids[offs[t]:offs[t + 1]])
+        compare_state(cache, pc, T)
+        # every id maps to slot*vpo + id%vpo and the pool row holds the table row
+        r = got_rows.cpu().numpy().astype(np.int64)
+        for t in range(T):
+            seg = ids[offs[t]:offs[t + 1]]
+            sm = pc.slot_map(t)
+            assert np.array_equal(r[offs[t]:offs[t + 1]], sm[seg // cache.vpo] * cache.vpo + seg % cache.vpo)
+            assert np.array_equal(cache.pool[got_rows[offs[t]:offs[t + 1]].long()].cpu().numpy(), expect[t][seg])
+        # "train": bump the looked-up rows in the pool, mirror it in the numpy model
+        uniq = torch.unique(got_rows.long())
+        cache.pool[uniq] += 1.0
+        for t in range(T):
+            u = np.unique(ids[offs[t]:offs[t + 1]])
+            expect[t][u] += 1.0
+        cache.reclaim()
+        pc.reclaim()
+        compare_state(cache, pc, T)
+    cache.flush()
+    for t in range(T):
+        assert np.array_equal(cache.store[t], expect[t]), "store of table %d after flush" % t
+    cache.close()
+
+
+def test_cache_reports_bad_id_and_exhausted_pool():
+    from dlrm_amd.cache import EmbeddingCache
+    cache = EmbeddingCache([100], 32, cache_size=4, num_slots=2, rows_per_page=1)
+    cache.write()
+    rows = cache.get_emb_vectors(torch.tensor([5, 100], dtype=torch.int64, device="cuda"), [0, 2])
+    torch.cuda.synchronize()
+    assert rows.cpu().tolist()[1] == -1 and cache.state().error_flags & 1
+    cache.get_emb_vectors(torch.tensor([1, 2, 3], dtype=torch.int64, device="cuda"), [0, 3])
+    assert cache.state().error_flags & 2          # 4 pages wanted, 2 slots
+    cache.close()
+
+
+def test_rmc1_reference_run_matches_reference_csv():
+    """The reference's own RMC1 run (LRU_BASE_RMC1_C2_B40_D200.csv) replayed
+    through the HBM cache: same ids (torch::manual_seed(0) dataset), same loop
+    (src/dlrmtest.cpp:468-545), per-batch totals of pages read and written
+    must equal the CSV's."""
+    from dlrm_amd.cache import EmbeddingCache
+    cfg = GOLD["rmc1"]
+    T, D, L = cfg["tables"], cfg["dim"], cfg["lookups"]
+    B, N, c, rows = cfg["batch"], cfg["data_size"], cfg["cache_mult"], cfg["rows_per_table"]
+    _, ids, _ = reference_dataset(T, L, B, N, rows)
+    cap = c * T * L * B
+    cache = EmbeddingCache([rows] * T, D, cache_size=cap, num_slots=cap + T * L * B + 1024)
+    trace = []
+    for epoch in range(1, cfg["epochs"] + 1):
+        for b, (s, bs) in enumerate(reference_batches(N, B)):
+            per_table = [np.sort(ids[s:s + bs, t * L:(t + 1) * L].reshape(-1)) for t in range(T)]
+            offs = np.concatenate([[0], np.cumsum([x.size for x in per_table])])
+            cache.get_emb_vectors(torch.from_numpy(np.concatenate(per_table)).cuda(), offs)
+            reads = cache.counters(reset=True)["read"]
+            cache.reclaim()
+            writes = cache.counters(reset=True)["write"]
+            if b + 1 == c and epoch == 1:
+                cache.cache_size = cache.page_count
+            trace.append({"read": int(reads.sum()), "write": int(writes.sum())})
+    assert cache.state().error_flags == 0
+    assert trace == cfg["batches"]
+    cache.close()

@@ -20,6 +20,9 @@ CASES = [
     (4, 19, 64, [64, 1, 7, 300], 5, True),
     (2, 5, 512, [30, 40], 9, True),
     (1, 3, 20, [11], 4, True),
+    (1, 1000, 64, [2], 1, False),            # two rows: runs of ~500, cut into segments and recombined
+    (2, 300, 128, [1, 5], 3, False),         # one row hit 900 times
+    (1, 256, 32, [1], 1, False),             # run length an exact multiple of the segment length
 ]
 
 
