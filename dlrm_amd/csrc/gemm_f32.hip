@@ -47,55 +47,60 @@ struct GemmParams {
     const float *mask;    // [M,N] (ld mask_ld) or NULL: C = (mask > 0) ? C : 0
     int64_t mask_ld;
     int a_vec, b_vec;     // operand rows are 16-byte aligned: 16-byte global loads allowed
-    int k_per_split;      // reduction elements per blockIdx.z (multiple of BK)
+    int gx, gy, gz;       // logical grid: column tiles, row tiles, reduction splits
+    int k_per_split;      // reduction elements per split (multiple of BK)
     int64_t slab_stride;  // elements between the partial outputs of consecutive splits
 };
 
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
 // RC: tile rows are output indices, 32 reduction elements (128 B) each: 8 lanes per row.
 // RS: tile rows are reduction indices, 128 output elements (512 B) each: 32 lanes per row.
-// `fast` (uniform over the workgroup): the whole 128 x 32 tile is in range and rows are 16-byte
-// aligned -- four unconditional 16-byte loads with no control flow around them, so all of them
-// are in flight together.  Otherwise every element is guarded (edge tiles, reduction tails,
-// unaligned operands).
+//
+// Both loaders are branch-free, so that all of a step's loads are in flight together and the
+// compiler can leave them outstanding across the MFMA block (a guarded load makes hipcc wait
+// for each one in turn):
+//   load_tile_vec    16-byte loads.  Needs 16-byte aligned rows and a full 32-deep reduction
+//                    step; RC tiles may run past the last output row (rows are clamped), RS
+//                    tiles must be full in the output index.
+//   load_tile_scalar 4-byte loads from clamped addresses + zero select: any shape / alignment.
 template <bool RC>
-__device__ inline void load_tile(const float *__restrict__ base, int64_t ld, int o0, int o_end, int r0, int r_end,
-                                 bool fast, float4 (&reg)[4]) {
+__device__ inline void load_tile_vec(const float *__restrict__ base, int64_t ld, int o0, int o_end, int r0,
+                                     float4 (&reg)[4]) {
     const int tid = threadIdx.x;
-    if (fast) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float *p;
-            if constexpr (RC) p = base + (int64_t)(o0 + (tid >> 3) + 32 * u) * ld + r0 + (tid & 7) * 4;
-            else p = base + (int64_t)(r0 + (tid >> 5) + 8 * u) * ld + o0 + (tid & 31) * 4;
-            reg[u] = *reinterpret_cast<const float4 *>(p);
+    for (int u = 0; u < 4; u++) {
+        if constexpr (RC) {
+            const int o = o0 + (tid >> 3) + 32 * u;
+            const int oc = o < o_end ? o : o_end - 1;
+            // rows past the end are read from the last row: they only feed output rows that
+            // the epilogue never stores, so no zeroing is needed
+            reg[u] = *reinterpret_cast<const float4 *>(base + (int64_t)oc * ld + r0 + (tid & 7) * 4);
+        } else {
+            reg[u] = *reinterpret_cast<const float4 *>(base + (int64_t)(r0 + (tid >> 5) + 8 * u) * ld + o0 +
+                                                       (tid & 31) * 4);
         }
-        return;
     }
+}
+
+template <bool RC>
+__device__ inline void load_tile_scalar(const float *__restrict__ base, int64_t ld, int o0, int o_end, int r0,
+                                        int r_end, float4 (&reg)[4]) {
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         int o, r;
         if constexpr (RC) { o = o0 + (tid >> 3) + 32 * u; r = r0 + (tid & 7) * 4; }
         else { r = r0 + (tid >> 5) + 8 * u; o = o0 + (tid & 31) * 4; }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (RC) {
-            if (o < o_end) {
-                const float *p = base + (int64_t)o * ld + r;
-                if (r < r_end) v.x = p[0];
-                if (r + 1 < r_end) v.y = p[1];
-                if (r + 2 < r_end) v.z = p[2];
-                if (r + 3 < r_end) v.w = p[3];
-            }
-        } else {
-            if (r < r_end) {
-                const float *p = base + (int64_t)r * ld + o;
-                if (o < o_end) v.x = p[0];
-                if (o + 1 < o_end) v.y = p[1];
-                if (o + 2 < o_end) v.z = p[2];
-                if (o + 3 < o_end) v.w = p[3];
-            }
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int oo = RC ? o : o + q, rr = RC ? r + q : r;
+            const bool ok = oo < o_end && rr < r_end;
+            const int oc = oo < o_end ? oo : o_end - 1, rc = rr < r_end ? rr : r_end - 1;
+            const float x = RC ? base[(int64_t)oc * ld + rc] : base[(int64_t)rc * ld + oc];
+            e[q] = ok ? x : 0.f;
         }
-        reg[u] = v;
+        reg[u] = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
 
@@ -126,6 +131,27 @@ __device__ inline void load_frag(const float *__restrict__ s, int o_base, int q,
     }
 }
 
+// 64 MFMAs: one 32-deep reduction step of the wave's 64x64 output
+template <bool A_RC, bool B_RC>
+__device__ inline void mfma_step(const float *__restrict__ sa, const float *__restrict__ sb, int wr, int wc,
+                                 f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float fa[2][4], fb[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) load_frag<A_RC>(sa, wr * 64 + mi * 32, q, fa[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) load_frag<B_RC>(sb, wc * 64 + ni * 32, q, fb[ni]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+}
+
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_MAX];
@@ -133,10 +159,18 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_begin = blockIdx.z * p.k_per_split;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the linear
+    // id so that every XCD works through one contiguous run of tiles (column tile fastest):
+    // the tiles that share an operand row-block are then resident on the same L2 together.
+    const int nwg = p.gx * p.gy * p.gz;
+    const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int bx = tile % p.gx, by = (tile / p.gx) % p.gy, bz = tile / (p.gx * p.gy);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int k_begin = bz * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int steps = (k_end - k_begin + BK - 1) / BK;
+    const int full_steps = (k_end - k_begin) / BK;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -146,43 +180,45 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
-    // tiles whose 128 output indices are all in range can use the unguarded loads
-    const bool a_full = p.a_vec && m0 + BM <= p.M, b_full = p.b_vec && n0 + BN <= p.N;
+    // can this workgroup's tiles take the 16-byte loader on full reduction steps?
+    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + BM <= p.M) && (B_RC || n0 + BN <= p.N);
+
     float4 ra[4], rb[4];
     if (steps > 0) {
-        const bool kf = k_begin + BK <= k_end;
-        load_tile<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, a_full && kf, ra);
-        load_tile<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, b_full && kf, rb);
+        load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra);
+        load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb);
         store_tile<A_RC>(smem[0][0], ra);
         store_tile<B_RC>(smem[0][1], rb);
     }
     __syncthreads();
 
-    for (int st = 0; st < steps; st++) {
+    int st = 0;
+    if (vec_tile) {
+        // steady state: the next step is a full one; straight-line code, loads stay in flight
+        // behind the 64 MFMAs of the current step
+        for (; st + 1 < full_steps; st++) {
+            const int cur = st & 1;
+            const int r0 = k_begin + (st + 1) * BK;
+            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, r0, ra);
+            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, r0, rb);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block
+            mfma_step<A_RC, B_RC>(smem[cur][0], smem[cur][1], wr, wc, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile<A_RC>(smem[cur ^ 1][0], ra);
+            store_tile<B_RC>(smem[cur ^ 1][1], rb);
+            __syncthreads();
+        }
+    }
+    // edge tiles, unaligned operands and the (partial) last steps
+    for (; st < steps; st++) {
         const int cur = st & 1;
         const bool more = st + 1 < steps;
         if (more) {
             const int r0 = k_begin + (st + 1) * BK;
-            const bool kf = r0 + BK <= k_end;
-            load_tile<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, a_full && kf, ra);
-            load_tile<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, b_full && kf, rb);
+            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, ra);
+            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, rb);
         }
-        const float *sa = smem[cur][0], *sb = smem[cur][1];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float fa[2][4], fb[2][4];
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) load_frag<A_RC>(sa, wr * 64 + mi * 32, q, fa[mi]);
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++) load_frag<B_RC>(sb, wc * 64 + ni * 32, q, fb[ni]);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ni++)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
-        }
+        mfma_step<A_RC, B_RC>(smem[cur][0], smem[cur][1], wr, wc, acc);
         if (more) {
             store_tile<A_RC>(smem[cur ^ 1][0], ra);
             store_tile<B_RC>(smem[cur ^ 1][1], rb);
@@ -191,7 +227,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
     }
 
     // epilogue: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
-    float *C = p.C + (int64_t)blockIdx.z * p.slab_stride;
+    float *C = p.C + (int64_t)bz * p.slab_stride;
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) {
         const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
@@ -249,9 +285,11 @@ __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__
 }
 
 template <bool A_RC, bool B_RC>
-static int launch_gemm(const GemmParams &p, int splits, hipStream_t s) {
-    dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.M, BM), (unsigned)splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), grid, dim3(kGemmThreads), 0, s, p);
+static int launch_gemm(GemmParams p, int splits, hipStream_t s) {
+    p.gx = (int)ceil_div(p.N, BN); p.gy = (int)ceil_div(p.M, BM); p.gz = splits;
+    const int64_t nwg = (int64_t)p.gx * p.gy * p.gz;
+    DLRM_REQUIRE(nwg < (1ll << 31), "GEMM grid too large");
+    hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

@@ -27,14 +27,18 @@ def sorted_batch(rng, rows_list, n_per_table):
 
 def compare_state(cache, pc, T):
     st = cache.state()
-    assert st.error_flags == 0
+    # flag 4 (a page of the current call was evicted) is a warning to the caller: it fires when
+    # the capacity is smaller than one batch, which some of these configurations are on purpose
+    assert st.error_flags & ~4 == 0
     assert st.page_count == pc.page_count
     assert st.ring_head == pc.L.orc_pagecache_ring_head(pc.h) and st.ring_tail == pc.L.orc_pagecache_ring_tail(pc.h)
     cnt = cache.counters()
     for name in ("read", "write", "hit", "miss"):
         assert np.array_equal(cnt[name], pc.counters(name)), name
     for t in range(T):
-        assert np.array_equal(cache.page_map(t).astype(np.int64), pc.slot_map(t)), "slot map of table %d" % t
+        got = cache.page_map(t).astype(np.int64)
+        ref = pc.slot_map(t)                      # the oracle's tables are all padded to the largest one
+        assert np.array_equal(got, ref[:got.size]) and (ref[got.size:] == -1).all(), "slot map of table %d" % t
 
 
 @pytest.mark.parametrize("dim,vpo,idx_t", [(32, None, torch.int64), (128, 1, torch.int32), (16, 4, torch.int64)])
