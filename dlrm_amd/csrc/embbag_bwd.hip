@@ -282,17 +282,22 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
 #pragma unroll
         for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
 
-    for (;;) {
-        const uint32_t g = (uint32_t)vals[j];
+    // scaled gradient row of occurrence jj, added into acc (mask = 0 drops a padding slot)
+    auto bag_ptr_scale = [&](int64_t jj, float mask, float &sc) -> const float * {
+        const uint32_t g = (uint32_t)vals[jj];
         const uint32_t t = g / (uint32_t)p.B;
         const uint32_t b = g - t * (uint32_t)p.B;
-        float sc = 1.0f;
+        sc = mask;
         if (p.mean) {
-            const int64_t s = (int64_t)off[g];
-            const int64_t e = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
-            sc = 1.0f / (float)(e - s);
+            const int64_t s0 = (int64_t)off[g];
+            const int64_t e0 = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
+            sc = mask / (float)(e0 - s0);
         }
-        const float *gp = p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
+        return p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
+    };
+    {
+        float sc;
+        const float *gp = bag_ptr_scale(j, 1.0f, sc);
 #pragma unroll
         for (int c = 0; c < NC; c++)
             if (col_ok[c]) {
@@ -302,9 +307,36 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
                 for (int q = 0; q < NF; q++) acc[c][q] += v[q] * sc;
             }
         j++;
-        if (j >= seg_end || keys[j] != k) break;
     }
-    const bool run_end = p.last_wins || j >= p.n_idx || keys[j] != k;
+    // further occurrences of the same row, kRunUnroll at a time: their gradient rows are fetched
+    // together (slots past the end of the run re-read occurrence j with weight 0, so the loads
+    // need no branches and stay in flight together); the sum keeps position order
+    constexpr int kRunUnroll = 8;
+    while (j < seg_end && keys[j] == k) {
+        const float *gp[kRunUnroll];
+        float sc[kRunUnroll];
+#pragma unroll
+        for (int u = 0; u < kRunUnroll; u++) {
+            const int64_t jj = j + u;
+            const bool ok = jj < seg_end && keys[jj < p.n_idx ? jj : p.n_idx - 1] == k;
+            gp[u] = bag_ptr_scale(ok ? jj : j, ok ? 1.0f : 0.0f, sc[u]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) {
+                float v[kRunUnroll][NF];
+#pragma unroll
+                for (int u = 0; u < kRunUnroll; u++) load_grad<NF>(gp[u] + col[c], v[u]);
+#pragma unroll
+                for (int u = 0; u < kRunUnroll; u++)
+#pragma unroll
+                    for (int q = 0; q < NF; q++) acc[c][q] += v[u][q] * sc[u];
+            }
+        j += kRunUnroll;
+    }
+    // does the run go on past this segment?
+    const bool continues = !p.last_wins && seg_end < p.n_idx && keys[seg_end - 1] == k && keys[seg_end] == k;
+    const bool run_end = !continues;
     if ((run_start || p.last_wins) && run_end) {
         apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
     } else {
@@ -349,15 +381,28 @@ __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, 
         for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
         if (col_ok[c]) load_vec<NF>(src + col[c], acc[c]);
     }
-    for (int64_t cc = c0 + 1; cc * kSegLen < p.n_idx && keys[cc * kSegLen] == k; cc++) {
-        const float *pp = partial + 2 * cc * (int64_t)dpad;
+    constexpr int kU = 8;
+    const int64_t n_seg = (p.n_idx + kSegLen - 1) / kSegLen;
+    for (int64_t cc = c0 + 1; cc < n_seg && keys[cc * kSegLen] == k; cc += kU) {
+        const float *pp[kU];
+        float m[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int64_t cu = cc + u;
+            const bool ok = cu < n_seg && keys[(cu < n_seg ? cu : cc) * kSegLen] == k;
+            pp[u] = partial + 2 * (ok ? cu : cc) * (int64_t)dpad;
+            m[u] = ok ? 1.0f : 0.0f;
+        }
 #pragma unroll
         for (int c = 0; c < NC; c++)
             if (col_ok[c]) {
-                float v[NF];
-                load_vec<NF>(pp + col[c], v);
+                float v[kU][NF];
 #pragma unroll
-                for (int q = 0; q < NF; q++) acc[c][q] += v[q];
+                for (int u = 0; u < kU; u++) load_vec<NF>(pp[u] + col[c], v[u]);
+#pragma unroll
+                for (int u = 0; u < kU; u++)
+#pragma unroll
+                    for (int q = 0; q < NF; q++) acc[c][q] += v[u][q] * m[u];
             }
     }
     apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);

@@ -185,8 +185,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 
     float4 ra[4], rb[4];
     if (steps > 0) {
-        load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra);
-        load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb);
+        if (vec_tile && full_steps > 0) {
+            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, k_begin, ra);
+            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, k_begin, rb);
+        } else {
+            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra);
+            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb);
+        }
         store_tile<A_RC>(smem[0][0], ra);
         store_tile<B_RC>(smem[0][1], rb);
     }

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks (HIP-event timed, inputs resident in HBM).
+
+    python tools/microbench.py gemm            # MLP GEMM shapes of the MLPerf model
+    python tools/microbench.py embbag          # BASELINE config 5: L x D x mode x dtype sweep
+    python tools/microbench.py sparse          # fused sparse backward, uniform and Zipf ids
+    python tools/microbench.py interact
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dlrm_amd import _capi, ops  # noqa: E402
+from dlrm_amd.data import zipf_ids  # noqa: E402
+
+
+def timeit(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def gemm():
+    M = 65536
+    shapes = [(1024, 1024), (1024, 479), (512, 1024), (256, 512), (512, 13), (256, 512), (128, 256), (1, 256)]
+    out = []
+    for N, K in shapes:
+        x = torch.randn(M, pad4(K), device="cuda")[:, :K]
+        w = torch.randn(N, pad4(K), device="cuda")[:, :K]
+        b = torch.randn(N, device="cuda")
+        y = torch.empty(M, pad4(N), device="cuda")[:, :N]
+        dz = torch.randn(M, pad4(N), device="cuda")[:, :N]
+        dx = torch.empty(M, pad4(K), device="cuda")[:, :K]
+        dw = torch.empty(N, pad4(K), device="cuda")[:, :K]
+        db = torch.empty(N, device="cuda")
+        ws = torch.empty(ops.linear_backward_weight_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+        fl = 2.0 * M * N * K
+        t_f = timeit(lambda: ops.linear_forward(x, w, b, True, out=y))
+        t_d = timeit(lambda: ops.linear_backward_data(dz, w, relu_mask=x, out=dx))
+        t_w = timeit(lambda: ops.linear_backward_weight(dz, x, dw=dw, db=db, workspace=ws))
+        rec = {"M": M, "N": N, "K": K, "fwd_TF": fl / t_f / 1e12, "bwd_data_TF": fl / t_d / 1e12,
+               "bwd_weight_TF": fl / t_w / 1e12, "fwd_us": t_f * 1e6, "bwd_data_us": t_d * 1e6, "bwd_weight_us": t_w * 1e6}
+        out.append(rec)
+        print(json.dumps(rec))
+    return out
+
+
+def embbag(rows=10_000_000, B=65536):
+    out = []
+    for D in (64, 128, 256):
+        for dt in (torch.float32, torch.bfloat16):
+            w = torch.empty(rows, D, device="cuda", dtype=dt)
+            ops.table_init_uniform_(w, 1)
+            for L in (1, 2, 4, 8, 16, 32, 64, 128):
+                n = B * L
+                for dist in ("uniform", "zipf"):
+                    g = torch.Generator(device="cuda").manual_seed(L)
+                    if dist == "zipf":
+                        idx = zipf_ids(n, rows, 1.05, g, "cuda").to(torch.int32)
+                    else:
+                        idx = torch.randint(0, rows, (n,), generator=g, device="cuda", dtype=torch.int32)
+                    off = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
+                    o = torch.empty(B, D, device="cuda")
+                    for mode in ("sum", "mean"):
+                        pool = _capi.POOL_MEAN if mode == "mean" else _capi.POOL_SUM
+                        t = timeit(lambda: ops.embbag_forward(w, idx, off, B, 1, None, pool, True, out=o, out_ld=D),
+                                   iters=5, warmup=1)
+                        byt = n * D * w.element_size() + B * D * 4 + n * 4 + (B + 1) * 4
+                        rec = {"op": "fwd", "D": D, "rows": "bf16" if dt == torch.bfloat16 else "f32", "L": L,
+                               "ids": dist, "mode": mode, "us": t * 1e6, "GBps": byt / t / 1e9}
+                        out.append(rec)
+                        print(json.dumps(rec))
+            del w
+    return out
+
+
+def sparse(rows=10_000_000, B=65536):
+    out = []
+    for D in (64, 128, 256):
+        for dt in (torch.float32, torch.bfloat16):
+            w = torch.empty(rows, D, device="cuda", dtype=dt)
+            ops.table_init_uniform_(w, 1)
+            for L in (1, 8, 32, 128):
+                n = B * L
+                for dist in ("uniform", "zipf"):
+                    g = torch.Generator(device="cuda").manual_seed(L)
+                    if dist == "zipf":
+                        idx = zipf_ids(n, rows, 1.05, g, "cuda").to(torch.int32)
+                    else:
+                        idx = torch.randint(0, rows, (n,), generator=g, device="cuda", dtype=torch.int32)
+                    U = int(torch.unique(idx).numel())
+                    off = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
+                    grad = torch.randn(B, D, device="cuda")
+                    ws = [None]
+
+                    def run():
+                        ws[0] = ops.embbag_backward_update(w, idx, off, B, grad, 1, None, _capi.POOL_SUM, True,
+                                                           lr=0.0, workspace=ws[0])
+                    t = timeit(run, iters=5, warmup=1)
+                    byt = B * D * 4 + 2 * U * D * w.element_size() + n * 4
+                    rec = {"op": "bwd_sgd", "D": D, "rows": "bf16" if dt == torch.bfloat16 else "f32", "L": L,
+                           "ids": dist, "unique": U, "us": t * 1e6, "GBps": byt / t / 1e9}
+                    out.append(rec)
+                    print(json.dumps(rec))
+            del w
+    return out
+
+
+def interact(B=65536, F=27, D=128):
+    x = torch.randn(B, F, D, device="cuda")
+    n_out = D + F * (F - 1) // 2
+    ld = pad4(n_out)
+    o = torch.empty(B, ld, device="cuda")
+    do = torch.randn(B, ld, device="cuda")
+    dx = torch.empty_like(x)
+    t_f = timeit(lambda: ops.interact_dot_forward(x, out=o, out_ld=ld))
+    t_b = timeit(lambda: ops.interact_dot_backward(x, do[:, :n_out], relu_mask_feature0=True, out=dx))
+    rec = {"fwd_us": t_f * 1e6, "fwd_GBps": B * (F * D + n_out) * 4 / t_f / 1e9, "bwd_us": t_b * 1e6,
+           "bwd_GBps": B * (2 * F * D + n_out) * 4 / t_b / 1e9}
+    print(json.dumps(rec))
+    return rec
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    res = {"gemm": gemm, "embbag": embbag, "sparse": sparse, "interact": interact}[which]()
+    if len(sys.argv) > 2:
+        json.dump(res, open(sys.argv[2], "w"), indent=1)
