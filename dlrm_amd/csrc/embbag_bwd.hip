@@ -203,17 +203,14 @@ __device__ inline void store_vec(float *g, const float (&v)[NF]) {
     }
 }
 
-// optimizer step on row k with the summed gradient acc (each touched row is read and written once)
+// optimizer step on row k given its current values w and its summed gradient acc
 template <typename ROW, int VEC16, int G, int NC>
-__device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
-                                        const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
+__device__ inline void apply_loaded(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
+                                    float (&w)[NC][RowRW<ROW, VEC16>::NF], const int (&col)[NC],
+                                    const bool (&col_ok)[NC], int lig) {
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
-    float w[NC][NF];
     const int64_t e0 = k * p.D;
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-        if (col_ok[c]) RW::load(p.w, e0 + col[c], w[c]);
     float mult = p.lr;
     if (p.adagrad) {
         float ss = 0.f;
@@ -238,88 +235,65 @@ __device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&a
         }
 }
 
-// One G-lane group per sorted position; the group on the first position of a segment (run start or
-// multiple of kSegLen) sums the segment.  A segment that is a whole run is applied at once; pieces
-// of longer runs go to `partial` (2 slots per kSegLen positions: [0] the piece that starts on the
-// boundary, [1] the piece that ends on it) and are combined by combine_runs_kernel.
-template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
-__global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
-                                                                     const int32_t *__restrict__ vals,
-                                                                     float *__restrict__ partial, int dpad) {
+// (each touched row is read once and written once)
+template <typename ROW, int VEC16, int G, int NC>
+__device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
+                                        const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
-    constexpr int GROUPS = kBwdThreads / G;
-    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
-    const int64_t i = (int64_t)blockIdx.x * GROUPS + grp;
-    if (i >= p.n_idx) return;
-    const KEY k = keys[i];
-    if ((int64_t)k >= p.total_rows) return;      // out-of-range index, reported by the expand kernel
-    const bool run_start = i == 0 || keys[i - 1] != k;
-    const IDX *off = static_cast<const IDX *>(p.off);
-    int64_t j, seg_end;
-    if (p.last_wins) {
-        // the reference's write-back keeps only the last occurrence (src/dlrmtest.cpp:96-101)
-        if (i + 1 < p.n_idx && keys[i + 1] == k) return;
-        j = i;
-        seg_end = i + 1;
-    } else {
-        if (!run_start && (i % kSegLen) != 0) return;
-        j = i;
-        seg_end = (i / kSegLen + 1) * kSegLen;
-        if (seg_end > p.n_idx) seg_end = p.n_idx;
-    }
-
-    int col[NC];
-    bool col_ok[NC];
+    float w[NC][NF];
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        col[c] = (c * G + lig) * NF;
-        col_ok[c] = col[c] < p.D;
+    for (int c = 0; c < NC; c++)
+        if (col_ok[c]) RW::load(p.w, k * p.D + col[c], w[c]);
+    apply_loaded<ROW, VEC16, G, NC>(p, k, acc, w, col, col_ok, lig);
+}
+
+// gradient row pointer and scale of occurrence jj (mask = 0 turns a padding slot into a no-op)
+template <typename IDX>
+__device__ inline const float *occurrence(const BwdParams &p, const int32_t *__restrict__ vals, int64_t jj,
+                                          float mask, float &sc) {
+    const IDX *off = static_cast<const IDX *>(p.off);
+    const uint32_t g = (uint32_t)vals[jj];
+    const uint32_t t = g / (uint32_t)p.B;
+    const uint32_t b = g - t * (uint32_t)p.B;
+    sc = mask;
+    if (p.mean) {
+        const int64_t s0 = (int64_t)off[g];
+        const int64_t e0 = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
+        sc = mask / (float)(e0 - s0);
     }
+    return p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
+}
+
+// Sum of the gradient rows of the occurrences of row k in sorted positions [i, seg_end) and either
+// the optimizer step (the piece is a whole run) or a store to `partial` (pieces of longer runs:
+// 2 slots per kSegLen positions, [0] the piece that starts on the boundary, [1] the piece that
+// ends on it; combine_runs_kernel adds them up).
+template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
+__device__ inline void sum_segment(const BwdParams &p, const KEY *__restrict__ keys, const int32_t *__restrict__ vals,
+                                   float *__restrict__ partial, int dpad, int64_t i, KEY k, bool run_start,
+                                   const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
+    constexpr int NF = RowRW<ROW, VEC16>::NF;
+    int64_t seg_end = (i / kSegLen + 1) * kSegLen;
+    if (seg_end > p.n_idx) seg_end = p.n_idx;
     float acc[NC][NF];
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
         for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
-
-    // scaled gradient row of occurrence jj, added into acc (mask = 0 drops a padding slot)
-    auto bag_ptr_scale = [&](int64_t jj, float mask, float &sc) -> const float * {
-        const uint32_t g = (uint32_t)vals[jj];
-        const uint32_t t = g / (uint32_t)p.B;
-        const uint32_t b = g - t * (uint32_t)p.B;
-        sc = mask;
-        if (p.mean) {
-            const int64_t s0 = (int64_t)off[g];
-            const int64_t e0 = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
-            sc = mask / (float)(e0 - s0);
-        }
-        return p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
-    };
-    {
-        float sc;
-        const float *gp = bag_ptr_scale(j, 1.0f, sc);
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (col_ok[c]) {
-                float v[NF];
-                load_grad<NF>(gp + col[c], v);
-#pragma unroll
-                for (int q = 0; q < NF; q++) acc[c][q] += v[q] * sc;
-            }
-        j++;
-    }
-    // further occurrences of the same row, kRunUnroll at a time: their gradient rows are fetched
-    // together (slots past the end of the run re-read occurrence j with weight 0, so the loads
-    // need no branches and stay in flight together); the sum keeps position order
+    // occurrences kRunUnroll at a time: their gradient rows are fetched together (slots past the
+    // end of the run re-read occurrence j with weight 0, so the loads need no branches and stay
+    // in flight together); the sum keeps position order
     constexpr int kRunUnroll = 8;
-    while (j < seg_end && keys[j] == k) {
+    int64_t j = i;
+    do {
         const float *gp[kRunUnroll];
         float sc[kRunUnroll];
 #pragma unroll
         for (int u = 0; u < kRunUnroll; u++) {
             const int64_t jj = j + u;
             const bool ok = jj < seg_end && keys[jj < p.n_idx ? jj : p.n_idx - 1] == k;
-            gp[u] = bag_ptr_scale(ok ? jj : j, ok ? 1.0f : 0.0f, sc[u]);
+            gp[u] = occurrence<IDX>(p, vals, ok ? jj : j, ok ? 1.0f : 0.0f, sc[u]);
         }
 #pragma unroll
         for (int c = 0; c < NC; c++)
@@ -333,11 +307,9 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
                     for (int q = 0; q < NF; q++) acc[c][q] += v[u][q] * sc[u];
             }
         j += kRunUnroll;
-    }
-    // does the run go on past this segment?
-    const bool continues = !p.last_wins && seg_end < p.n_idx && keys[seg_end - 1] == k && keys[seg_end] == k;
-    const bool run_end = !continues;
-    if ((run_start || p.last_wins) && run_end) {
+    } while (j < seg_end && keys[j] == k);
+    const bool continues = seg_end < p.n_idx && keys[seg_end - 1] == k && keys[seg_end] == k;
+    if (run_start && !continues) {
         apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
     } else {
         float *dst = partial + (2 * (i / kSegLen) + ((i % kSegLen) == 0 ? 0 : 1)) * (int64_t)dpad;
@@ -345,6 +317,101 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
         for (int c = 0; c < NC; c++)
             if (col_ok[c]) store_vec<NF>(dst + col[c], acc[c]);
     }
+}
+
+// Each G-lane group owns kPosPerGroup consecutive sorted positions.
+//  * Rows that occur once in the batch (the common case on large tables): their gradient rows and
+//    the table rows of all of the group's positions are fetched together, updated and stored --
+//    kPosPerGroup independent row read-modify-writes in flight per group.
+//  * A position that starts a longer run (or sits on a kSegLen boundary inside one) sums its piece
+//    of the run (sum_segment).
+// DLRM_DUP_LAST_WINS: only the last occurrence of a row counts, which makes every row a
+// single-occurrence update of that position.
+constexpr int kPosPerGroup = 4;
+
+template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
+__global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
+                                                                     const int32_t *__restrict__ vals,
+                                                                     float *__restrict__ partial, int dpad) {
+    using RW = RowRW<ROW, VEC16>;
+    constexpr int NF = RW::NF;
+    constexpr int GROUPS = kBwdThreads / G;
+    constexpr int P = kPosPerGroup;
+    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
+    const int64_t i0 = ((int64_t)blockIdx.x * GROUPS + grp) * P;
+    if (i0 >= p.n_idx) return;
+
+    // keys of positions i0-1 .. i0+P; positions outside [0, n) read as "no row"
+    const KEY none = ~(KEY)0;
+    KEY kw[P + 2];
+#pragma unroll
+    for (int u = 0; u < P + 2; u++) {
+        const int64_t idx = i0 - 1 + u;
+        kw[u] = (idx >= 0 && idx < p.n_idx) ? keys[idx] : none;
+    }
+    bool fast[P], slow[P], any_fast = false;
+#pragma unroll
+    for (int u = 0; u < P; u++) {
+        const KEY k = kw[u + 1];
+        const bool valid = (int64_t)k < p.total_rows && k != none;   // bad indices carry key == total_rows
+        const bool run_start = kw[u] != k, next_same = kw[u + 2] == k;
+        if (p.last_wins) {
+            fast[u] = valid && !next_same;
+            slow[u] = false;
+        } else {
+            fast[u] = valid && run_start && !next_same;
+            slow[u] = valid && !fast[u] && (run_start || ((i0 + u) % kSegLen) == 0);
+        }
+        any_fast |= fast[u];
+    }
+
+    int col[NC];
+    bool col_ok[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        col[c] = (c * G + lig) * NF;
+        col_ok[c] = col[c] < p.D;
+    }
+
+    if (any_fast) {
+        // slots that are not single-occurrence rows re-read the group's first fast slot
+        int first = 0;
+#pragma unroll
+        for (int u = P - 1; u >= 0; u--)
+            if (fast[u]) first = u;
+        const float *gp[P];
+        float sc[P];
+        int64_t row[P];
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+            const int uu = fast[u] ? u : first;
+            row[u] = (int64_t)kw[uu + 1];
+            gp[u] = occurrence<IDX>(p, vals, i0 + uu, 1.0f, sc[u]);
+        }
+        float g[P][NC][NF], w[P][NC][NF];
+#pragma unroll
+        for (int u = 0; u < P; u++)
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (col_ok[c]) {
+                    load_grad<NF>(gp[u] + col[c], g[u][c]);
+                    RW::load(p.w, row[u] * p.D + col[c], w[u][c]);
+                }
+#pragma unroll
+        for (int u = 0; u < P; u++)
+            if (fast[u]) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int q = 0; q < NF; q++) g[u][c][q] *= sc[u];
+                apply_loaded<ROW, VEC16, G, NC>(p, row[u], g[u], w[u], col, col_ok, lig);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < P; u++)
+        if (slow[u])
+            sum_segment<IDX, KEY, ROW, VEC16, G, NC>(p, keys, vals, partial, dpad, i0 + u, kw[u + 1], kw[u] != kw[u + 1],
+                                                     col, col_ok, lig);
 }
 
 // One group per kSegLen positions: if a run starts inside this stretch and goes on beyond it, sum
@@ -411,7 +478,7 @@ __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, 
 template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
 static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, float *partial, int dpad,
                          hipStream_t s) {
-    const int64_t blocks = ceil_div(p.n_idx, kBwdThreads / G);
+    const int64_t blocks = ceil_div(p.n_idx, (int64_t)(kBwdThreads / G) * kPosPerGroup);
     hipLaunchKernelGGL((sparse_update_kernel<IDX, KEY, ROW, VEC16, G, NC>), dim3((unsigned)blocks),
                        dim3(kBwdThreads), 0, s, p, keys, vals, partial, dpad);
     DLRM_LAUNCH_CHECK();

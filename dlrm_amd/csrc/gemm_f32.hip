@@ -50,6 +50,8 @@ struct GemmParams {
     int gx, gy, gz;       // logical grid: column tiles, row tiles, reduction splits
     int k_per_split;      // reduction elements per split (multiple of BK)
     int64_t slab_stride;  // elements between the partial outputs of consecutive splits
+    float *colsum;        // RS A operand only: [splits][M] sums of A over this split's reduction range
+                          // (the bias gradient of the weight-gradient product), or NULL
 };
 
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
@@ -197,6 +199,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
     }
     __syncthreads();
 
+    // bias gradient: column sums of dz fall out of the A tiles already staged in LDS; the
+    // workgroups of the first column tile accumulate them, one output row per thread
+    float csum = 0.f;
+    const bool do_colsum = !A_RC && p.colsum != nullptr && bx == 0 && tid < BM;
+    auto add_colsum = [&](const float *sa) {
+        if constexpr (!A_RC) {
+            if (do_colsum) {
+#pragma unroll 8
+                for (int r = 0; r < BK; r++) csum += sa[r * BM + tid];
+            }
+        }
+    };
+
     int st = 0;
     if (vec_tile) {
         // steady state: the next step is a full one; straight-line code, loads stay in flight
@@ -207,6 +222,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
             load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, r0, ra);
             load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, r0, rb);
             __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block
+            add_colsum(smem[cur][0]);
             mfma_step<A_RC, B_RC>(smem[cur][0], smem[cur][1], wr, wc, acc);
             __builtin_amdgcn_sched_barrier(0);
             store_tile<A_RC>(smem[cur ^ 1][0], ra);
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
             load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, ra);
             load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, rb);
         }
+        add_colsum(smem[cur][0]);
         mfma_step<A_RC, B_RC>(smem[cur][0], smem[cur][1], wr, wc, acc);
         if (more) {
             store_tile<A_RC>(smem[cur ^ 1][0], ra);
@@ -230,6 +247,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
         }
         __syncthreads();
     }
+
+    if (do_colsum && m0 + tid < p.M) p.colsum[(int64_t)bz * p.M + m0 + tid] = csum;
 
     // epilogue: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
     float *C = p.C + (int64_t)bz * p.slab_stride;
@@ -264,24 +283,6 @@ __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
         const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
         out[(int64_t)r * ld_out + c] = a;
     }
-}
-
-// column sums of an [M,N] matrix: one workgroup per 64 columns, partial sums
-// over row slices are combined through LDS; slices across workgroups go to
-// partial[slice][n] and are reduced by reduce_slabs_kernel
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int64_t ld, int M, int N,
-                                                      int rows_per_slice, float *__restrict__ partial) {
-    __shared__ float s[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
-    const int m_begin = blockIdx.y * rows_per_slice;
-    const int m_end = min(M, m_begin + rows_per_slice);
-    float a = 0.f;
-    if (n < N)
-        for (int m = m_begin + w; m < m_end; m += 4) a += x[(int64_t)m * ld + n];
-    s[w][lane] = a;
-    __syncthreads();
-    if (w == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = s[0][lane] + s[1][lane] + s[2][lane] + s[3][lane];
 }
 
 __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__ g, int64_t n, float lr) {
@@ -353,8 +354,7 @@ extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N,
     DLRM_REQUIRE(bytes != nullptr && M >= 0 && N >= 1 && K >= 1, "bad arguments");
     const int tiles = (int)(ceil_div(N, BM) * ceil_div(K, BN));
     const int splits = choose_splits((int)M, tiles);
-    const int slices = (int)ceil_div(M > 0 ? M : 1, 2048);
-    *bytes = sizeof(float) * ((size_t)splits * N * K + (size_t)slices * N) + 256;
+    *bytes = sizeof(float) * ((size_t)splits * N * K + (size_t)splits * N) + 256;
     return DLRM_OK;
 }
 
@@ -379,11 +379,14 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
     p.M = l->N; p.N = l->K; p.K = (int)l->M;  // C = dW [N,K], reduction over the batch
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(ceil_div(l->M, splits), BK) * BK;
+    float *db_partial = slabs + (size_t)splits * l->N * l->K;
     if (splits == 1) {
         p.C = l->d_dw; p.ldc = l->dw_ld;
+        p.colsum = l->d_db;
         if (int rc = launch_gemm<false, false>(p, 1, s)) return rc;
     } else {
         p.C = slabs; p.ldc = l->K; p.slab_stride = (int64_t)l->N * l->K;
+        p.colsum = l->d_db ? db_partial : nullptr;
         const int real_splits = (int)ceil_div(l->M, p.k_per_split);
         if (int rc = launch_gemm<false, false>(p, real_splits, s)) return rc;
         const int64_t n = (int64_t)l->N * l->K;
@@ -391,16 +394,11 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, real_splits, p.slab_stride,
                            l->N, l->K, l->d_dw, l->dw_ld);
         DLRM_LAUNCH_CHECK();
-    }
-    if (l->d_db) {
-        float *partial = slabs + (size_t)splits * l->N * l->K;
-        const int slices = (int)ceil_div(l->M, 2048);
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(l->N, 64), (unsigned)slices), dim3(256), 0, s,
-                           l->d_dz, l->dz_ld, (int)l->M, l->N, 2048, partial);
-        DLRM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 256)), dim3(256), 0, s, partial, slices,
-                           (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
-        DLRM_LAUNCH_CHECK();
+        if (l->d_db) {
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 256)), dim3(256), 0, s, db_partial,
+                               real_splits, (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
+            DLRM_LAUNCH_CHECK();
+        }
     }
     return DLRM_OK;
 }

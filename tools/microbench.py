@@ -34,9 +34,9 @@ def pad4(n):
     return (n + 3) // 4 * 4
 
 
-def gemm():
+def gemm(shapes=None):
     M = 65536
-    shapes = [(1024, 1024), (1024, 479), (512, 1024), (256, 512), (512, 13), (256, 512), (128, 256), (1, 256)]
+    shapes = shapes or [(1024, 1024), (1024, 479), (512, 1024), (256, 512), (512, 13), (128, 256), (1, 256)]
     out = []
     for N, K in shapes:
         x = torch.randn(M, pad4(K), device="cuda")[:, :K]
@@ -137,6 +137,7 @@ def interact(B=65536, F=27, D=128):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    res = {"gemm": gemm, "embbag": embbag, "sparse": sparse, "interact": interact}[which]()
+    res = {"gemm": gemm, "gemm1024": lambda: gemm([(1024, 1024)]), "embbag": embbag, "sparse": sparse,
+           "interact": interact}[which]()
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
