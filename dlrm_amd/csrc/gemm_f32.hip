@@ -183,7 +183,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
             for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
     // can this workgroup's tiles take the 16-byte loader on full reduction steps?
-    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + BM <= p.M) && (B_RC || n0 + BN <= p.N);
+    // (an RS tile may run past the last output index as long as it stays inside the row's
+    //  leading dimension: the surplus columns only feed outputs that are never stored)
+    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + BM <= p.M || m0 + BM <= p.lda) &&
+                          (B_RC || n0 + BN <= p.N || n0 + BN <= p.ldb);
 
     float4 ra[4], rb[4];
     if (steps > 0) {
@@ -250,25 +253,58 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 
     if (do_colsum && m0 + tid < p.M) p.colsum[(int64_t)bz * p.M + m0 + tid] = csum;
 
-    // epilogue: register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile
+    // Epilogue.  Register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32
+    // tile: a row per register, so direct stores would be 4 bytes per lane.  Each wave instead
+    // parks its 64x64 block in LDS (the staging buffers are free now) and streams it out as
+    // 16-byte row segments -- 16 lanes per 256-byte row piece -- with bias / ReLU / mask fused.
     float *C = p.C + (int64_t)bz * p.slab_stride;
+    __syncthreads();
+    constexpr int CT_LD = 68;
+    float *ct = &smem[0][0][0] + wave * (64 * CT_LD);
 #pragma unroll
-    for (int ni = 0; ni < 2; ni++) {
-        const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++) {
+        for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) {
-                    float v = acc[mi][ni][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.mask) v = p.mask[(int64_t)m * p.mask_ld + n] > 0.f ? v : 0.f;
-                    C[(int64_t)m * p.ldc + n] = v;
-                }
+            for (int r = 0; r < 16; r++)
+                ct[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
+    __builtin_amdgcn_wave_barrier();
+    const int cn = n0 + wc * 64 + (lane & 15) * 4;
+    const bool c_vec = (reinterpret_cast<uintptr_t>(C) % 16 == 0) && (p.ldc % 4 == 0) &&
+                       (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+        if (cn < p.N) bv.x = p.bias[cn];
+        if (cn + 1 < p.N) bv.y = p.bias[cn + 1];
+        if (cn + 2 < p.N) bv.z = p.bias[cn + 2];
+        if (cn + 3 < p.N) bv.w = p.bias[cn + 3];
+    }
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m0 + wr * 64 + row;
+        float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane & 15) * 4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (m >= p.M || cn >= p.N) continue;
+        float *dst = C + (int64_t)m * p.ldc + cn;
+        if (c_vec && cn + 3 < p.N) {
+            if (p.mask) {
+                const float4 k = *reinterpret_cast<const float4 *>(p.mask + (int64_t)m * p.mask_ld + cn);
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+                v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
             }
+            *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (cn + q < p.N) {
+                    float x = e[q];
+                    if (p.mask) x = p.mask[(int64_t)m * p.mask_ld + cn + q] > 0.f ? x : 0.f;
+                    dst[q] = x;
+                }
         }
     }
 }

@@ -100,6 +100,13 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _padk(n):
+    """Leading dimension of a matrix whose columns are a GEMM reduction / output index: wide
+    ones are rounded up to whole 128-column tiles so that every tile of the fp32 GEMM can use
+    its 16-byte loader (the pad columns are zero and never stored to)."""
+    return _pad4(n) if n <= 128 else (n + 127) // 128 * 128
+
+
 class MLPStack:
     """A stack of Linear+ReLU layers (struct Net2's fc1..fc4, src/dlrmtest.cpp:234-272).
     Weights [N, pad4(K)] and biases live in one flat parameter buffer shared by
@@ -111,7 +118,7 @@ class MLPStack:
         self.W, self.b, self.dW, self.db = [], [], [], []
         o = offset
         for K, N in zip(sizes[:-1], sizes[1:]):
-            kp = _pad4(K)
+            kp = _padk(K)
             self.W.append(params[o:o + N * kp].view(N, kp)[:, :K])
             self.dW.append(grads[o:o + N * kp].view(N, kp)[:, :K])
             o += N * kp
@@ -122,7 +129,7 @@ class MLPStack:
 
     @staticmethod
     def param_count(sizes):
-        return sum(N * _pad4(K) + _pad4(N) for K, N in zip(sizes[:-1], sizes[1:]))
+        return sum(N * _padk(K) + _pad4(N) for K, N in zip(sizes[:-1], sizes[1:]))
 
     @property
     def n_layers(self):
@@ -216,23 +223,23 @@ class DLRM:
         if cfg.interaction == "dot":
             self.feat = torch.zeros((B, F * D), **f32)            # [B, F, D]; feature 0 = bottom output
             self.dfeat = torch.zeros((B, F * D), **f32)
-            self.inter_ld = _pad4(cfg.top_in)
+            self.inter_ld = _padk(cfg.top_in)
             self.inter = torch.zeros((B, self.inter_ld), **f32)
             self.dinter = torch.zeros((B, self.inter_ld), **f32)
             self.emb_col0 = D
         else:
             self.emb_col0 = cfg.bottom[-1]
-            self.inter_ld = _pad4(cfg.top_in)
+            self.inter_ld = _padk(cfg.top_in)
             self.feat = torch.zeros((B, self.inter_ld), **f32)    # [bottom out | pooled tables], read by the top MLP
             self.dfeat = torch.zeros((B, self.inter_ld), **f32)
             self.inter, self.dinter = self.feat, self.dfeat
-        self.bot_acts = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
+        self.bot_acts = [torch.zeros((B, _padk(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
         self.bot_acts.append(self.feat[:, :cfg.bottom[-1]])
-        self.bot_dz = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
-        self.top_acts = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.top[:-1]]
+        self.bot_dz = [torch.zeros((B, _padk(n)), **f32)[:, :n] for n in cfg.bottom[:-1]]
+        self.top_acts = [torch.zeros((B, _padk(n)), **f32)[:, :n] for n in cfg.top[:-1]]
         self.pred = torch.zeros((B, 1), **f32)
         self.top_acts.append(self.pred)
-        self.top_dz = [torch.zeros((B, _pad4(n)), **f32)[:, :n] for n in cfg.top[:-1]]
+        self.top_dz = [torch.zeros((B, _padk(n)), **f32)[:, :n] for n in cfg.top[:-1]]
         self.dpred = torch.zeros((B, 1), **f32)
         self.loss = torch.zeros(1, **f32)
         self.ws_dense = None
