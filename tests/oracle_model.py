@@ -92,3 +92,34 @@ def make_batch(rng, cfg, B, ragged=False):
     else:
         labels = rng.standard_normal(B).astype(np.float32)
     return dense, idx, off, labels
+
+
+def as_shipped_step(orc, tables, ids, x, target, W, b, L, lr=0.01):
+    """One batch of the reference's loop body as it executes (src/dlrmtest.cpp:53-107,
+    :191-197, :254-272, :499-535): per table the batch's SORTED ids, mean pooling over
+    consecutive groups of L sorted ids, concat after the bottom MLP output, ReLU on every
+    layer, MSE, plain SGD on table 0 only, written back last duplicate wins.  tables[0] is
+    updated in place.  Returns (loss, pred)."""
+    T = len(tables)
+    B = x.shape[0]
+    D = tables[0].shape[1]
+    off = np.arange(B + 1, dtype=np.int64) * L
+    pooled, sorted0 = [], None
+    for t in range(T):
+        s = np.sort(ids[:, t * L:(t + 1) * L].reshape(-1))
+        if t == 0:
+            sorted0 = s
+        pooled.append(orc.embbag_forward(tables[t], s, off, B, 1, None, orc.POOL_MEAN, include_last_offset=True))
+    h1 = orc.linear_forward(x, W[0], b[0], True)
+    h2 = orc.linear_forward(h1, W[1], b[1], True)
+    cat = np.concatenate([h2] + pooled, axis=1)
+    h3 = orc.linear_forward(cat, W[2], b[2], True)
+    pred = orc.linear_forward(h3, W[3], b[3], True)
+    loss, dpred = orc.mse_loss(pred.reshape(-1), np.asarray(target).reshape(-1))
+    d3, _, _ = orc.linear_backward(h3, W[3], pred, dpred.reshape(B, 1), True)
+    dcat, _, _ = orc.linear_backward(cat, W[2], h3, d3, True)
+    nb = h2.shape[1]
+    g0 = np.ascontiguousarray(dcat[:, nb:nb + D])
+    orc.embbag_backward_update(tables[0], sorted0, off, B, g0, 1, None, orc.POOL_MEAN, True, orc.OPT_SGD,
+                               orc.DUP_LAST_WINS, lr)
+    return loss, pred

@@ -66,33 +66,11 @@ def test_losses(oracle):
 
 
 def as_shipped_step_with(orc, c):
-    """The reference's loop body as it executes (src/dlrmtest.cpp:53-107,
-    :191-197, :254-272, :499-535) built from the oracle's operators: sorted
-    ids, mean pooling over consecutive groups of L sorted ids, concat, ReLU on
-    every layer, MSE, plain SGD on table 0 only, last duplicate wins."""
+    from tests.oracle_model import as_shipped_step
     T, L = int(c["T"]), int(c["L"])
-    ids, x, target = c["ids"], c["x"], c["target"].reshape(-1)
-    B = x.shape[0]
     tables = [c["table%d" % t].copy() for t in range(T)]
-    D = tables[0].shape[1]
-    pooled, sorted_ids = [], []
-    off = np.arange(B + 1, dtype=np.int64) * L
-    for t in range(T):
-        s = np.sort(ids[:, t * L:(t + 1) * L].reshape(-1))
-        sorted_ids.append(s)
-        pooled.append(orc.embbag_forward(tables[t], s, off, B, 1, None, orc.POOL_MEAN, include_last_offset=True))
-    h1 = orc.linear_forward(x, c["W0"], c["b0"], True)
-    h2 = orc.linear_forward(h1, c["W1"], c["b1"], True)
-    cat = np.concatenate([h2] + pooled, axis=1)
-    h3 = orc.linear_forward(cat, c["W2"], c["b2"], True)
-    pred = orc.linear_forward(h3, c["W3"], c["b3"], True)
-    loss, dpred = orc.mse_loss(pred.reshape(-1), target)
-    d3, _, _ = orc.linear_backward(h3, c["W3"], pred, dpred.reshape(B, 1), True)
-    dcat, _, _ = orc.linear_backward(cat, c["W2"], h3, d3, True)
-    nb = h2.shape[1]
-    g0 = np.ascontiguousarray(dcat[:, nb:nb + D])
-    orc.embbag_backward_update(tables[0], sorted_ids[0], off, B, g0, 1, None, orc.POOL_MEAN, True,
-                               orc.OPT_SGD, orc.DUP_LAST_WINS, 0.01)
+    loss, pred = as_shipped_step(orc, tables, c["ids"], c["x"], c["target"], [c["W%d" % i] for i in range(4)],
+                                 [c["b%d" % i] for i in range(4)], L)
     return loss, pred, tables
 
 
