@@ -25,11 +25,12 @@ class ShardingPlan:
         return first, len(self.tables_of_rank[rank])
 
 
-def plan_table_wise(table_rows, world, dim=1, bytes_per_elem=4, lookups_per_table=None):
-    """Greedy bin packing: biggest table first onto the rank with the lowest
-    load, where load = memory share + lookup share (both normalised to 1 per
-    rank), so that neither HBM footprint nor gather traffic piles up on one GPU.
-    Deterministic: ties go to the lower rank."""
+def plan_table_wise(table_rows, world, dim=1, bytes_per_elem=4, lookups_per_table=None, mem_cap_bytes=None):
+    """Greedy bin packing, biggest table first.  A table goes to the rank with the least gather
+    traffic so far (lookups), ties to the rank holding the fewest bytes, then to the lower rank;
+    ranks whose HBM budget (`mem_cap_bytes`, default: no limit -- all MLPerf tables together are
+    96 GB and fit one 288 GB GPU) the table would exceed are skipped.  Traffic, not footprint,
+    is what costs time per step, so it is the primary load.  Deterministic."""
     T = len(table_rows)
     if world < 1:
         raise ValueError("world must be >= 1")
@@ -37,14 +38,15 @@ def plan_table_wise(table_rows, world, dim=1, bytes_per_elem=4, lookups_per_tabl
     if len(lookups) != T:
         raise ValueError("lookups_per_table must have one entry per table")
     mem = [float(r) * dim * bytes_per_elem for r in table_rows]
-    tot_mem = sum(mem) or 1.0
-    tot_lk = float(sum(lookups)) or 1.0
-    order = sorted(range(T), key=lambda t: (-mem[t], t))
+    order = sorted(range(T), key=lambda t: (-lookups[t], -mem[t], t))
     load_mem = [0.0] * world
     load_lk = [0.0] * world
     owner = [0] * T
     for t in order:
-        best = min(range(world), key=lambda r: (load_mem[r] / tot_mem + load_lk[r] / tot_lk, r))
+        ranks = [r for r in range(world) if mem_cap_bytes is None or load_mem[r] + mem[t] <= mem_cap_bytes]
+        if not ranks:
+            raise ValueError("table %d (%d rows) does not fit any rank's memory budget" % (t, table_rows[t]))
+        best = min(ranks, key=lambda r: (load_lk[r], load_mem[r], r))
         owner[t] = best
         load_mem[best] += mem[t]
         load_lk[best] += lookups[t]

@@ -1,0 +1,116 @@
+"""world_size 2 on CPU (gloo): the sharded train step of dlrm_amd.model -- table-wise plan,
+all-to-all of pooled vectors and of their gradients, all-reduce of the MLP gradients,
+global-mean loss -- must give what one process gives on the whole batch.  Compute is the CPU
+oracle patched in for dlrm_amd.ops (tests/cpu_ops_shim.py): this exercises the exchange layout
+and the reduction logic, which is the part no single-GPU test can see."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dlrm_amd.sharding import plan_table_wise
+
+
+def test_plan_table_wise_balances_and_is_deterministic():
+    from dlrm_amd.model import MLPERF_TABLE_ROWS
+    p = plan_table_wise(MLPERF_TABLE_ROWS, 8, dim=128)
+    assert sorted(t for r in p.tables_of_rank for t in r) == list(range(26))
+    assert p == plan_table_wise(MLPERF_TABLE_ROWS, 8, dim=128)
+    counts = [len(r) for r in p.tables_of_rank]
+    assert max(counts) - min(counts) <= 1                     # equal lookups per table: traffic is balanced
+    mem = [sum(MLPERF_TABLE_ROWS[t] for t in r) for r in p.tables_of_rank]
+    assert max(mem) < 2 * 40_000_000                          # no rank holds two of the capped tables
+    with pytest.raises(ValueError):
+        plan_table_wise(MLPERF_TABLE_ROWS, 8, dim=128, mem_cap_bytes=1e9)
+    assert p.feature_order == [t for r in p.tables_of_rank for t in r]
+    first = 0
+    for r in range(8):
+        assert p.feature_slot(r) == (first, counts[r])
+        first += counts[r]
+    one = plan_table_wise([5, 7, 9], 1)
+    assert one.tables_of_rank == [[0, 1, 2]]
+    many = plan_table_wise([5, 7], 4)            # more ranks than tables: some ranks own nothing
+    assert sorted(len(r) for r in many.tables_of_rank) == [0, 0, 1, 1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _cfg(kind):
+    from dlrm_amd.model import DLRMConfig
+    if kind == "dot":
+        return DLRMConfig(table_rows=[50, 7, 300, 20, 64], dim=16, dense_in=13, bottom=[32, 16], top=[24, 1], lr=0.05,
+                          lookups=2)
+    return DLRMConfig(table_rows=[40, 9, 100], dim=8, dense_in=6, bottom=[16, 8], top=[12, 1], interaction="cat",
+                      loss="mse", final_relu=True, pooling="mean", lookups=3, lr=0.02)
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dlrm_amd import ops
+        from tests import cpu_ops_shim
+        cpu_ops_shim.install(ops)
+        from dlrm_amd.model import DLRM
+        from oracle import oracle as orc
+        from tests.oracle_model import make_batch, oracle_train_step
+
+        cfg = _cfg(kind)
+        Bl = 6
+        Bg = Bl * world
+        m = DLRM(cfg, Bl, device="cpu", rank=rank, world=world, seed=4)
+        if kind == "cat":
+            for b in m.bottom.b + m.top.b:
+                b.abs_()
+        rng = np.random.default_rng(123)                      # every rank draws the same global batches
+        # single-process reference state: all tables (global order), same dense parameters
+        tables = [orc.table_init_uniform(r * cfg.dim, (4 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+                  for t, r in enumerate(cfg.table_rows)]
+        Ws = [w.numpy().copy() for w in m.bottom.W + m.top.W]
+        bs = [b.numpy().copy() for b in m.bottom.b + m.top.b]
+        ok = True
+        for step in range(2):
+            dense, idx, off, labels = make_batch(rng, cfg, Bg)
+            L = cfg.lookups
+            # this rank's tables over the global batch
+            my = m.my_tables
+            idx_l = np.concatenate([idx[t * Bg * L:(t + 1) * Bg * L] for t in my]) if my else np.zeros(0, np.int64)
+            off_l = np.arange(len(my) * Bg + 1, dtype=np.int64) * L
+            sl = slice(rank * Bl, (rank + 1) * Bl)
+            m.load_batch(torch.from_numpy(dense[sl]), torch.from_numpy(labels[sl]))
+            loss = m.train_step(torch.from_numpy(idx_l), torch.from_numpy(off_l))
+            tot = loss.clone()
+            dist.all_reduce(tot)                               # per-rank shares add up to the global mean
+            loss_ref, pred_ref = oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                                   cfg.lr, feature_order=m.plan.feature_order)
+            ok &= abs(tot.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+            ok &= np.allclose(m.pred.numpy().reshape(-1), pred_ref[sl], rtol=1e-4, atol=1e-6)
+            tro = m.table_row_offsets.numpy()
+            for lt, t in enumerate(my):
+                ok &= np.allclose(m.weight[tro[lt]:tro[lt + 1]].numpy(), tables[t], rtol=1e-5, atol=1e-6)
+            for a, r in zip(m.bottom.W + m.top.W + m.bottom.b + m.top.b, Ws + bs):
+                ok &= np.allclose(a.numpy(), r, rtol=1e-4, atol=1e-6)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dot", "cat"])
+def test_sharded_step_equals_single_process(kind):
+    world = 2
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, kind, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
