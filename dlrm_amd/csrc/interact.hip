@@ -15,22 +15,42 @@
 namespace dlrm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kIntThreads = 256;
 constexpr int kIntWaves = kIntThreads / 64;
 constexpr int kFP = 32;  // padded feature count
 constexpr int kSLd = 36; // row stride of the 32x32 gradient tile
 
-__device__ inline void stage_sample(const float *__restrict__ xb, int F, int D, int ld, float *__restrict__ sx,
-                                    int lane) {
-    const int n4 = F * D / 4;
-    for (int i = lane; i < n4; i += 64) {
-        const float4 v = reinterpret_cast<const float4 *>(xb)[i];
+// A sample's [F, D] block travels global -> registers -> LDS so that the NEXT sample's loads are in
+// flight while the current one is being multiplied.  NV = ceil(F*D/4 / 64) 16-byte vectors per lane
+// is a template parameter: fully unrolled, only the last vector is partial, and the LDS offset of
+// every vector is computed once (no division in the loop, no branches around the loads).
+template <int NV>
+__device__ inline void sample_offsets(int n4, int D, int ld, int lane, int (&lds_off)[NV]) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        int i = lane + 64 * u;
+        if (i >= n4) i = n4 - 1;   // lanes past the end re-read the final vector and park it in the same place
         const int e = i * 4, row = e / D, col = e - row * D;
-        *reinterpret_cast<float4 *>(sx + row * ld + col) = v;
+        lds_off[u] = row * ld + col;
     }
 }
 
+template <int NV>
+__device__ inline void sample_fetch(const float *__restrict__ xb, int last_idx, int lane, f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int u = 0; u < NV - 1; u++) v[u] = reinterpret_cast<const f32x4 *>(xb)[lane + 64 * u];
+    v[NV - 1] = reinterpret_cast<const f32x4 *>(xb)[last_idx];
+}
+
+template <int NV>
+__device__ inline void sample_park(float *__restrict__ sx, const int (&lds_off)[NV], const f32x4 (&v)[NV]) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) *reinterpret_cast<f32x4 *>(sx + lds_off[u]) = v[u];
+}
+
+template <int NV>
 __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const float *__restrict__ x, int64_t B,
                                                                         int F, int D, float *__restrict__ out,
                                                                         int64_t out_ld) {
@@ -41,12 +61,23 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
     // rows F..31 stay zero for the whole kernel
     for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;
     const int n_pairs = F * (F - 1) / 2;
+    const int n4 = F * D / 4;
     const int row = lane & 31, h = lane >> 5;
+    const int64_t stride = (int64_t)gridDim.x * kIntWaves;
 
-    for (int64_t b = (int64_t)blockIdx.x * kIntWaves + wave; b < B; b += (int64_t)gridDim.x * kIntWaves) {
-        stage_sample(x + b * F * D, F, D, ld, sx, lane);
-        __builtin_amdgcn_wave_barrier();
+    int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
+    int lds_off[NV];
+    sample_offsets<NV>(n4, D, ld, lane, lds_off);
+    const int last_idx = min(lane + 64 * (NV - 1), n4 - 1);
+    f32x4 pre[NV];
+    sample_fetch<NV>(x + (b < B ? b : 0) * F * D, last_idx, lane, pre);
+    for (; b < B; b += stride) {
+        sample_park<NV>(sx, lds_off, pre);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        // next sample's loads fly behind the MFMAs (the last iteration re-reads its own sample)
+        sample_fetch<NV>(x + (b + stride < B ? b + stride : b) * F * D, last_idx, lane, pre);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -71,6 +102,7 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const float *__restrict__ x,
                                                                         const float *__restrict__ dout,
                                                                         int64_t dout_ld, int64_t B, int F, int D,
@@ -81,27 +113,63 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
     float *sx = smem + (size_t)wave * (kFP * ld + kFP * kSLd);
     float *ss = sx + kFP * ld;
     for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;
+    // the gradient tile only ever has entries (i,j), (j,i) with j < i < F written: zero it once
+    for (int i = lane; i < kFP * kSLd; i += 64) ss[i] = 0.f;
     const int n_pairs = F * (F - 1) / 2;
+    const int n4 = F * D / 4;
     const int row = lane & 31, h = lane >> 5;
+    const int64_t stride = (int64_t)gridDim.x * kIntWaves;
+    // this lane's pair indices c = lane, lane+64, ... and their (i, j): c = i(i-1)/2 + j, 0 <= j < i
+    constexpr int kMaxPairs = (kFP * (kFP - 1) / 2 + 63) / 64;   // 8
+    int pij[kMaxPairs];
+#pragma unroll
+    for (int u = 0; u < kMaxPairs; u++) {
+        const int c = lane + 64 * u;
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)c)) * 0.5f);
+        while (i * (i - 1) / 2 > c) i--;
+        while ((i + 1) * i / 2 <= c) i++;
+        const int j = c - i * (i - 1) / 2;
+        pij[u] = c < n_pairs ? (i << 8) | j : -1;
+    }
 
-    for (int64_t b = (int64_t)blockIdx.x * kIntWaves + wave; b < B; b += (int64_t)gridDim.x * kIntWaves) {
-        stage_sample(x + b * F * D, F, D, ld, sx, lane);
-        const float *go = dout + b * dout_ld;
-        for (int i = lane; i < kFP * kSLd; i += 64) ss[i] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        for (int c = lane; c < n_pairs; c += 64) {
-            // c = i(i-1)/2 + j, 0 <= j < i
-            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)c)) * 0.5f);
-            while (i * (i - 1) / 2 > c) i--;
-            while ((i + 1) * i / 2 <= c) i++;
-            const int j = c - i * (i - 1) / 2;
-            const float g = go[D + c];
-            ss[i * kSLd + j] = g;
-            ss[j * kSLd + i] = g;
+    // LDS offsets of this lane's pair gradients (lanes past the last pair write a spare cell)
+    int sij[kMaxPairs], sji[kMaxPairs];
+#pragma unroll
+    for (int u = 0; u < kMaxPairs; u++) {
+        const int i = pij[u] >= 0 ? pij[u] >> 8 : kFP - 1, j = pij[u] >= 0 ? pij[u] & 255 : kFP - 1;
+        sij[u] = i * kSLd + j;     // (31,31) is never read as a gradient: F <= 32 rows, row 31 pairs only with j < 31
+        sji[u] = j * kSLd + i;
+    }
+    int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
+    int lds_off[NV];
+    sample_offsets<NV>(n4, D, ld, lane, lds_off);
+    const int last_idx = min(lane + 64 * (NV - 1), n4 - 1);
+    f32x4 pre[NV];
+    float pg[kMaxPairs];
+    auto fetch_grad = [&](int64_t bb) {
+        const float *go = dout + bb * dout_ld + D;
+#pragma unroll
+        for (int u = 0; u < kMaxPairs; u++) pg[u] = go[pij[u] >= 0 ? lane + 64 * u : 0];
+    };
+    sample_fetch<NV>(x + (b < B ? b : 0) * F * D, last_idx, lane, pre);
+    fetch_grad(b < B ? b : 0);
+    for (; b < B; b += stride) {
+        sample_park<NV>(sx, lds_off, pre);
+#pragma unroll
+        for (int u = 0; u < kMaxPairs; u++) {
+            const float g = pij[u] >= 0 ? pg[u] : 0.f;
+            ss[sij[u]] = g;
+            ss[sji[u]] = g;
         }
-        __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int64_t nb = b + stride < B ? b + stride : b;
+            sample_fetch<NV>(x + nb * F * D, last_idx, lane, pre);
+            fetch_grad(nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float *go = dout + b * dout_ld;
         // A fragments of S' = S + S^T: 4 chunks of 8 reduction (feature) indices
         float4 fa[4];
 #pragma unroll
@@ -148,7 +216,7 @@ using namespace dlrm;
 static int check_interact(const float *d_x, int64_t B, int32_t F, int32_t D) {
     DLRM_REQUIRE(B >= 0 && F >= 1 && D >= 1, "bad shape B=%lld F=%d D=%d", (long long)B, F, D);
     DLRM_REQUIRE(F <= kFP, "dot interaction supports at most %d features, got %d", kFP, F);
-    DLRM_REQUIRE(D % 8 == 0 && D <= 512, "dot interaction needs dim %% 8 == 0 and dim <= 512, got %d", D);
+    DLRM_REQUIRE(D % 8 == 0 && F * D <= 4096, "dot interaction needs dim %% 8 == 0 and F*dim <= 4096, got F=%d dim=%d", F, D);
     DLRM_REQUIRE(B == 0 || (d_x != nullptr && reinterpret_cast<uintptr_t>(d_x) % 16 == 0), "x must be 16-byte aligned");
     return DLRM_OK;
 }
@@ -161,10 +229,21 @@ extern "C" int dlrm_interact_dot_forward(const float *d_x, int64_t B, int32_t F,
     const size_t lds = sizeof(float) * kIntWaves * kFP * (D + 4);
     const int64_t want = ceil_div(B, kIntWaves);
     const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
-    DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(interact_dot_fwd_kernel, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), d_x, B, F, D,
-                       d_out, out_ld);
+    const int nv = (F * D / 4 + 63) / 64;
+#define DLRM_INT_FWD(NV)                                                                                            \
+    case NV:                                                                                                        \
+        DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_kernel<NV>),                   \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL(interact_dot_fwd_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), d_x, \
+                           B, F, D, d_out, out_ld);                                                                 \
+        break;
+    switch (nv) {
+        DLRM_INT_FWD(1) DLRM_INT_FWD(2) DLRM_INT_FWD(3) DLRM_INT_FWD(4) DLRM_INT_FWD(5) DLRM_INT_FWD(6) DLRM_INT_FWD(7)
+        DLRM_INT_FWD(8) DLRM_INT_FWD(9) DLRM_INT_FWD(10) DLRM_INT_FWD(11) DLRM_INT_FWD(12) DLRM_INT_FWD(13)
+        DLRM_INT_FWD(14) DLRM_INT_FWD(15) DLRM_INT_FWD(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_FWD
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -179,10 +258,21 @@ extern "C" int dlrm_interact_dot_backward(const float *d_x, const float *d_dout,
     const size_t lds = sizeof(float) * kIntWaves * (kFP * (D + 4) + kFP * kSLd);
     const int64_t want = ceil_div(B, kIntWaves);
     const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
-    DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(interact_dot_bwd_kernel, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), d_x, d_dout,
-                       dout_ld, B, F, D, d_dx, relu_mask_feature0);
+    const int nv = (F * D / 4 + 63) / 64;
+#define DLRM_INT_BWD(NV)                                                                                            \
+    case NV:                                                                                                        \
+        DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_kernel<NV>),                   \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL(interact_dot_bwd_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), d_x, \
+                           d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0);                                     \
+        break;
+    switch (nv) {
+        DLRM_INT_BWD(1) DLRM_INT_BWD(2) DLRM_INT_BWD(3) DLRM_INT_BWD(4) DLRM_INT_BWD(5) DLRM_INT_BWD(6) DLRM_INT_BWD(7)
+        DLRM_INT_BWD(8) DLRM_INT_BWD(9) DLRM_INT_BWD(10) DLRM_INT_BWD(11) DLRM_INT_BWD(12) DLRM_INT_BWD(13)
+        DLRM_INT_BWD(14) DLRM_INT_BWD(15) DLRM_INT_BWD(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_BWD
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
