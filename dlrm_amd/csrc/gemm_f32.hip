@@ -21,6 +21,8 @@
 // next 4), RS operands [32][128] (ds_read_b32 fragments).  MFMA j of a group
 // of four consumes r = 8q+j on lanes 0..31 and r = 8q+4+j on lanes 32..63 for
 // both operands, so the pairing of reduction indices is consistent.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dlrm {
@@ -133,6 +135,69 @@ __device__ inline void load_frag(const float *__restrict__ s, int o_base, int q,
     }
 }
 
+// Epilogue.  Register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile: a row
+// per register, so direct stores would be 4 bytes per lane.  Each wave instead parks 32 rows of its
+// 64x64 block at a time in LDS (`ct`: 4 waves x 32 x 68 floats, the staging buffers are free by
+// now) and streams them out as 16-byte row segments -- 16 lanes per 256-byte row piece -- with
+// bias / ReLU / mask fused.
+__device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[2][2], float *ct_all, int m0, int n0,
+                                    int bz) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    float *C = p.C + (int64_t)bz * p.slab_stride;
+    constexpr int CT_LD = 68;
+    float *ct = ct_all + wave * (32 * CT_LD);
+    const int cn = n0 + wc * 64 + (lane & 15) * 4;
+    const bool c_vec = (reinterpret_cast<uintptr_t>(C) % 16 == 0) && (p.ldc % 4 == 0) &&
+                       (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+        if (cn < p.N) bv.x = p.bias[cn];
+        if (cn + 1 < p.N) bv.y = p.bias[cn + 1];
+        if (cn + 2 < p.N) bv.z = p.bias[cn + 2];
+        if (cn + 3 < p.N) bv.w = p.bias[cn + 3];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                ct[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m0 + wr * 64 + mi * 32 + row;
+            float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane & 15) * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (m >= p.M || cn >= p.N) continue;
+            float *dst = C + (int64_t)m * p.ldc + cn;
+            if (c_vec && cn + 3 < p.N) {
+                if (p.mask) {
+                    const float4 k = *reinterpret_cast<const float4 *>(p.mask + (int64_t)m * p.mask_ld + cn);
+                    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+                    v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (cn + q < p.N) {
+                        float x = e[q];
+                        if (p.mask) x = p.mask[(int64_t)m * p.mask_ld + cn + q] > 0.f ? x : 0.f;
+                        dst[q] = x;
+                    }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // 64 MFMAs: one 32-deep reduction step of the wave's 64x64 output
 template <bool A_RC, bool B_RC>
 __device__ inline void mfma_step(const float *__restrict__ sa, const float *__restrict__ sb, int wr, int wc,
@@ -159,7 +224,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_MAX];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the linear
     // id so that every XCD works through one contiguous run of tiles (column tile fastest):
@@ -253,60 +318,235 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 
     if (do_colsum && m0 + tid < p.M) p.colsum[(int64_t)bz * p.M + m0 + tid] = csum;
 
-    // Epilogue.  Register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32
-    // tile: a row per register, so direct stores would be 4 bytes per lane.  Each wave instead
-    // parks its 64x64 block in LDS (the staging buffers are free now) and streams it out as
-    // 16-byte row segments -- 16 lanes per 256-byte row piece -- with bias / ReLU / mask fused.
-    float *C = p.C + (int64_t)bz * p.slab_stride;
-    __syncthreads();
-    constexpr int CT_LD = 68;
-    float *ct = &smem[0][0][0] + wave * (64 * CT_LD);
+    __syncthreads();   // the staging buffers are free now
+    store_output(p, acc, reinterpret_cast<float *>(&smem[0][0][0]), m0, n0, bz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same product, three times faster matrix pipe: every float32 operand element is split exactly into
+// three bf16 pieces a = a0 + a1 + a2 (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); the
+// pieces together carry 24+ mantissa bits, |a - (a0+a1+a2)| <= 2^-27 |a|) and the product is
+// evaluated as the six leading cross terms a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on
+// v_mfma_f32_32x32x16_bf16 with float32 accumulation.  Products of bf16 pieces are exact in float32
+// and the dropped terms are below 2^-26 |ab|, so the result carries float32 accuracy (measured
+// against a float64 reference it is as close as the float32 MFMA path) at 6 x 32 cycles per 16-deep
+// step instead of 8 x 64.  The split happens once per element when a tile goes from registers to
+// LDS: three bf16 planes per operand.
+//   RC planes: [128][32] bf16, 80-byte rows (conflict-free ds_read_b128 fragments of 8 k-values)
+//   RS planes: [32][128] bf16, 256-byte rows with the 16-byte chunks XOR-swizzled; fragments come
+//              out of the hardware transposing read ds_read_b64_tr_b16 (two per fragment)
+// One LDS stage (61 KB) + register prefetch, two barriers per step, 2 workgroups per CU.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPlaneBytes = 128 * 80;   // RC plane; an RS plane (32 x 256 B) is smaller
+constexpr int kRcRowBytes = 80;
+
+__device__ inline void split3(const float4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const __bf16 a0 = (__bf16)e[q];
+        const float r1 = e[q] - (float)a0;
+        const __bf16 a1 = (__bf16)r1;
+        const float r2 = r1 - (float)a1;
+        h[q] = a0; m[q] = a1; l[q] = (__bf16)r2;
+    }
+}
+
+__device__ inline int rs_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch of row `row`
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <bool RC>
+__device__ inline void store_planes(unsigned char *__restrict__ planes, const float4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int off;
+        if constexpr (RC) off = ((tid >> 3) + 32 * u) * kRcRowBytes + (tid & 7) * 8;
+        else off = rs_chunk_off((tid >> 5) + 8 * u, (tid & 31) >> 1) + 8 * (tid & 1);
+        bf16x4 h, m, l;
+        split3(reg[u], h, m, l);
+        *reinterpret_cast<bf16x4 *>(planes + off) = h;
+        *reinterpret_cast<bf16x4 *>(planes + kPlaneBytes + off) = m;
+        *reinterpret_cast<bf16x4 *>(planes + 2 * kPlaneBytes + off) = l;
+    }
+}
+
+// 8 consecutive reduction elements (16-deep chunk kc, lane half h takes 8h..8h+7) of output index
+// o_base + (lane & 31), from one plane
+template <bool RC>
+__device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, int o_base, int kc) {
+    const int lane = threadIdx.x & 63;
+    if constexpr (RC) {
+        return *reinterpret_cast<const bf16x8 *>(plane + (o_base + (lane & 31)) * kRcRowBytes + kc * 32 + (lane >> 5) * 16);
+    } else {
+        // per 16-lane group the transposing read takes a 4-row x 16-column block; lane 4q+p of the
+        // group supplies the address of row q, columns 4p..4p+3, and lane i receives column i
+        const int li = lane & 15, g = lane >> 4, h = g >> 1;
+        const int q = li >> 2, pp = li & 3;
+        const int ch = (o_base >> 3) + 2 * (g & 1) + (pp >> 1);
+        const int row0 = kc * 16 + 8 * h + q;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_s16x4 *)(plane + rs_chunk_off(row0, ch) + 8 * (pp & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_s16x4 *)(plane + rs_chunk_off(row0 + 4, ch) + 8 * (pp & 1)));
+        const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, t);
+    }
+}
+
+// Compiler fence for register values: uses of `reg` after this point cannot be moved above it.
+// Keeps the bf16 split of a prefetched tile behind the MFMA block (it is plain arithmetic on the
+// loaded registers, which the compiler would otherwise start as soon as the loads are issued,
+// waiting for them with the whole MFMA block still to come).
+__device__ inline void pin_here(float4 (&reg)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) asm volatile("" : "+v"(reg[u].x), "+v"(reg[u].y), "+v"(reg[u].z), "+v"(reg[u].w));
+}
+
+// 48 MFMAs: one 32-deep reduction step of the wave's 64x64 output
+template <bool A_RC, bool B_RC>
+__device__ inline void mfma_step_bf16x3(const unsigned char *__restrict__ pa, const unsigned char *__restrict__ pb, int wr,
+                                        int wc, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+            for (int mi = 0; mi < 2; mi++) a[mi][pl] = load_frag16<A_RC>(pa + pl * kPlaneBytes, wr * 64 + mi * 32, kc);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) b[ni][pl] = load_frag16<B_RC>(pb + pl * kPlaneBytes, wc * 64 + ni * 32, kc);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) {
+                f32x16 c = acc[mi][ni];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+    }
+}
+
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * kPlaneBytes];
+    unsigned char *pa = smem, *pb = smem + 3 * kPlaneBytes;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nwg = p.gx * p.gy * p.gz;
+    const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int bx = tile % p.gx, by = (tile / p.gx) % p.gy, bz = tile / (p.gx * p.gy);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int k_begin = bz * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int steps = (k_end - k_begin + BK - 1) / BK;
+    const int full_steps = (k_end - k_begin) / BK;
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                ct[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
-    __builtin_amdgcn_wave_barrier();
-    const int cn = n0 + wc * 64 + (lane & 15) * 4;
-    const bool c_vec = (reinterpret_cast<uintptr_t>(C) % 16 == 0) && (p.ldc % 4 == 0) &&
-                       (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) {
-        if (cn < p.N) bv.x = p.bias[cn];
-        if (cn + 1 < p.N) bv.y = p.bias[cn + 1];
-        if (cn + 2 < p.N) bv.z = p.bias[cn + 2];
-        if (cn + 3 < p.N) bv.w = p.bias[cn + 3];
-    }
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 4 + (lane >> 4);
-        const int m = m0 + wr * 64 + row;
-        float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane & 15) * 4);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (m >= p.M || cn >= p.N) continue;
-        float *dst = C + (int64_t)m * p.ldc + cn;
-        if (c_vec && cn + 3 < p.N) {
-            if (p.mask) {
-                const float4 k = *reinterpret_cast<const float4 *>(p.mask + (int64_t)m * p.mask_ld + cn);
-                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
-                v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4 *>(dst) = v;
-        } else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+
+    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + BM <= p.M || m0 + BM <= p.lda) &&
+                          (B_RC || n0 + BN <= p.N || n0 + BN <= p.ldb);
+
+    // bias gradient (weight-gradient product only): this thread's four output rows of the A tile,
+    // summed over every staged reduction row
+    const bool do_colsum = !A_RC && p.colsum != nullptr && bx == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_colsum = [&](const float4 (&ra)[4]) {
+        if constexpr (!A_RC) {
+            if (do_colsum) {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (cn + q < p.N) {
-                    float x = e[q];
-                    if (p.mask) x = p.mask[(int64_t)m * p.mask_ld + cn + q] > 0.f ? x : 0.f;
-                    dst[q] = x;
-                }
+                for (int u = 0; u < 4; u++) { cs.x += ra[u].x; cs.y += ra[u].y; cs.z += ra[u].z; cs.w += ra[u].w; }
+            }
+        }
+    };
+
+    float4 ra[4], rb[4];
+    if (steps > 0) {
+        if (vec_tile && full_steps > 0) {
+            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, k_begin, ra);
+            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, k_begin, rb);
+        } else {
+            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra);
+            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb);
+        }
+        add_colsum(ra);
+        store_planes<A_RC>(pa, ra);
+        store_planes<B_RC>(pb, rb);
+    }
+    __syncthreads();
+
+    int st = 0;
+    if (vec_tile) {
+        for (; st + 1 < full_steps; st++) {
+            const int r0 = k_begin + (st + 1) * BK;
+            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, r0, ra);
+            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, r0, rb);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block
+            mfma_step_bf16x3<A_RC, B_RC>(pa, pb, wr, wc, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                    // every wave is done reading the planes
+            pin_here(ra);
+            pin_here(rb);
+            add_colsum(ra);
+            store_planes<A_RC>(pa, ra);
+            store_planes<B_RC>(pb, rb);
+            __syncthreads();
         }
     }
+    for (; st < steps; st++) {
+        const bool more = st + 1 < steps;
+        if (more) {
+            const int r0 = k_begin + (st + 1) * BK;
+            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, ra);
+            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, rb);
+        }
+        mfma_step_bf16x3<A_RC, B_RC>(pa, pb, wr, wc, acc);
+        __syncthreads();
+        if (more) {
+            add_colsum(ra);
+            store_planes<A_RC>(pa, ra);
+            store_planes<B_RC>(pb, rb);
+        }
+        __syncthreads();
+    }
+
+    float *fsm = reinterpret_cast<float *>(smem);
+    if constexpr (!A_RC) {
+        if (do_colsum) {
+            // thread (tid>>5, tid&31) holds the sums of output rows 4*(tid&31).. over its reduction rows
+            *reinterpret_cast<float4 *>(fsm + (tid >> 5) * BM + (tid & 31) * 4) = cs;
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; w++) a += fsm[w * BM + tid];
+                p.colsum[(int64_t)bz * p.M + m0 + tid] = a;
+            }
+            __syncthreads();
+        }
+    }
+    store_output(p, acc, fsm, m0, n0, bz);
 }
 
 // out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out)
@@ -326,12 +566,25 @@ __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__
         w[i] -= lr * g[i];
 }
 
+static int g_gemm_mode = -1;   // -1: not chosen yet (environment, else default); 0: f32 MFMA; 1: bf16x3 split
+
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char *e = getenv("DLRM_GEMM_MODE");
+        g_gemm_mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_gemm_mode;
+}
+
 template <bool A_RC, bool B_RC>
 static int launch_gemm(GemmParams p, int splits, hipStream_t s) {
     p.gx = (int)ceil_div(p.N, BN); p.gy = (int)ceil_div(p.M, BM); p.gz = splits;
     const int64_t nwg = (int64_t)p.gx * p.gy * p.gz;
     DLRM_REQUIRE(nwg < (1ll << 31), "GEMM grid too large");
-    hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
+    if (gemm_mode() == 1)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -354,6 +607,14 @@ static int choose_splits(int M_red, int tiles) {
 }  // namespace dlrm
 
 using namespace dlrm;
+
+extern "C" int dlrm_set_gemm_mode(int32_t mode) {
+    DLRM_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (f32 MFMA) or 1 (bf16x3 split), got %d", mode);
+    g_gemm_mode = mode;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_get_gemm_mode(void) { return gemm_mode(); }
 
 extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     DLRM_REQUIRE(l != nullptr, "linear descriptor is NULL");

@@ -262,3 +262,13 @@ def copy_2d_(dst, src):
     check(_capi.lib().dlrm_copy_2d(_ptr(dst), C.c_int64(_ld(dst)), _ptr(src), C.c_int64(_ld(src)),
                                    C.c_int64(dst.shape[0]), C.c_int64(dst.shape[1]), _stream()))
     return dst
+
+
+def set_gemm_mode(mode):
+    """0: float32 MFMA (v_mfma_f32_32x32x2_f32); 1: exact bf16x3 split products on the bf16 MFMA
+    with float32 accumulation (float32 accuracy, 8/3 of the matrix-pipe rate)."""
+    check(_capi.lib().dlrm_set_gemm_mode(int(mode)))
+
+
+def get_gemm_mode():
+    return int(_capi.lib().dlrm_get_gemm_mode())

@@ -161,6 +161,18 @@ typedef struct dlrm_linear {
 int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream);
 
 /*
+ * How the float32 MLP products are evaluated on the matrix cores (no counterpart in the reference,
+ * whose GEMMs are libtorch sgemm calls):
+ *   0  v_mfma_f32_32x32x2_f32: float32 operands, an exact k-ordered fma chain
+ *   1  (default) every operand element is split exactly into three bf16 pieces and the product is
+ *      formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16 with float32
+ *      accumulation: float32 accuracy (dropped terms < 2^-26 of a product) at 8/3 of the rate.
+ * The process-wide default can also be set with the environment variable DLRM_GEMM_MODE=0|1.
+ */
+int dlrm_set_gemm_mode(int32_t mode);
+int dlrm_get_gemm_mode(void);
+
+/*
  * Backward of the same layer; replaces the autograd pass loss.backward()
  * (src/dlrmtest.cpp:531) for the MLP.  dz is the gradient w.r.t. the
  * pre-activation z = x W^T + b.

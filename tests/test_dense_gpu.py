@@ -13,6 +13,16 @@ from tests.test_embbag_forward_gpu import rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x3"], autouse=True)
+def gemm_mode(request):
+    """every test of this file runs with both evaluations of the float32 products"""
+    from dlrm_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(old)
+
 SHAPES = [
     # M, N, K
     (60, 128, 256),     # reference RMC1 bottom layer 1 (batch 60)

@@ -137,6 +137,8 @@ def interact(B=65536, F=27, D=128):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    if os.environ.get("GEMM_MODE"):
+        ops.set_gemm_mode(int(os.environ["GEMM_MODE"]))
     res = {"gemm": gemm, "gemm1024": lambda: gemm([(1024, 1024)]), "embbag": embbag, "sparse": sparse,
            "interact": interact}[which]()
     if len(sys.argv) > 2:
