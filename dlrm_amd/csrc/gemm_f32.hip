@@ -23,6 +23,8 @@
 // both operands, so the pairing of reduction indices is consistent.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace dlrm {
@@ -323,73 +325,158 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Same product, three times faster matrix pipe: every float32 operand element is split exactly into
-// three bf16 pieces a = a0 + a1 + a2 (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); the
-// pieces together carry 24+ mantissa bits, |a - (a0+a1+a2)| <= 2^-27 |a|) and the product is
-// evaluated as the six leading cross terms a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on
-// v_mfma_f32_32x32x16_bf16 with float32 accumulation.  Products of bf16 pieces are exact in float32
-// and the dropped terms are below 2^-26 |ab|, so the result carries float32 accuracy (measured
-// against a float64 reference it is as close as the float32 MFMA path) at 6 x 32 cycles per 16-deep
-// step instead of 8 x 64.  The split happens once per element when a tile goes from registers to
-// LDS: three bf16 planes per operand.
-//   RC planes: [128][32] bf16, 80-byte rows (conflict-free ds_read_b128 fragments of 8 k-values)
-//   RS planes: [32][128] bf16, 256-byte rows with the 16-byte chunks XOR-swizzled; fragments come
+// Same product, faster matrix pipe: every float32 operand element is split exactly into three bf16
+// pieces a = a0 + a1 + a2 (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); the pieces
+// together carry 24+ mantissa bits, |a - (a0+a1+a2)| <= 2^-27 |a|) and the product is evaluated as
+// the six leading cross terms a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on v_mfma_f32_32x32x16_bf16
+// with float32 accumulation.  Products of bf16 pieces are exact in float32 and the dropped terms are
+// below 2^-26 |ab|, so the result carries float32 accuracy (measured against a float64 reference it
+// is as close as the float32 MFMA path) at 6 x 32 cycles per 16-deep step instead of 8 x 64.
+//
+// Pipeline.  Global tiles are 128 x 32 float32 per operand, loaded into registers two half-steps
+// before their first use.  LDS holds two stages of one 16-deep half-step each (three bf16 planes
+// per operand); while the 24 MFMAs of half-step j run out of stage j&1, the same wave splits the
+// next half-step's 16 elements per lane and writes them to the other stage, so the split's VALU
+// work and LDS writes sit in the shadow of the MFMAs and one barrier per half-step is enough.
+//   RC planes: [128][16] bf16, 32-byte rows whose two 16-byte chunks swap places in every other
+//              group of 8 rows (conflict-free ds_write_b64 of the pieces and ds_read_b128 fragments
+//              of 8 k-values)
+//   RS planes: [16][128] bf16, 256-byte rows with the 16-byte chunks XOR-swizzled; fragments come
 //              out of the hardware transposing read ds_read_b64_tr_b16 (two per fragment)
-// One LDS stage (61 KB) + register prefetch, two barriers per step, 2 workgroups per CU.
+// 48 KB of LDS per workgroup; the register budget allows two workgroups per CU.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPlaneBytes = 128 * 80;   // RC plane; an RS plane (32 x 256 B) is smaller
-constexpr int kRcRowBytes = 80;
+constexpr int kPlane16 = 4096;              // 128 x 16 bf16, RC or RS
+constexpr int kStage16 = 6 * kPlane16;      // A planes then B planes
 
-__device__ inline void split3(const float4 &v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
-    const float e[4] = {v.x, v.y, v.z, v.w};
+__device__ inline int rc_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch (0/1) of row `row`
+    return 32 * row + 16 * (ch ^ ((row >> 3) & 1));
+}
+
+// Register image of one 128 x 32 operand tile: reg[2h], reg[2h+1] belong to half-step h.
+//   RC: reg[2h+v] = row (tid>>2) + 64v, reduction elements 16h + 4(tid&3) .. +3
+//   RS: reg[2h+v] = reduction row 16h + (tid>>5) + 8v, output elements 4(tid&31) .. +3
+// Addresses are a wave-uniform tile origin (scalar registers) plus a per-thread byte offset that
+// does not change over the reduction loop.
+template <bool RC>
+struct TileAddr {
+    const float *origin;   // element (o0, 0) of the operand
+    int64_t ld;
+    int o0, o_end;
+    unsigned off[2];       // byte offsets of this thread's two 16-byte pieces inside a half tile
+};
+
+template <bool RC>
+__device__ inline TileAddr<RC> make_tile_addr(const float *base, int64_t ld, int o0, int o_end) {
+    TileAddr<RC> t;
+    const int tid = threadIdx.x;
+    t.ld = ld; t.o0 = o0; t.o_end = o_end;
+    if constexpr (RC) {
+        t.origin = base + (int64_t)o0 * ld;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const __bf16 a0 = (__bf16)e[q];
-        const float r1 = e[q] - (float)a0;
-        const __bf16 a1 = (__bf16)r1;
-        const float r2 = r1 - (float)a1;
-        h[q] = a0; m[q] = a1; l[q] = (__bf16)r2;
+        for (int v = 0; v < 2; v++) {
+            const int o = o0 + (tid >> 2) + 64 * v;
+            const int oc = o < o_end ? o : o_end - 1;   // surplus rows only feed outputs that are never stored
+            t.off[v] = (unsigned)((oc - o0) * (int)ld + (tid & 3) * 4) * 4u;
+        }
+    } else {
+        t.origin = base + o0;
+#pragma unroll
+        for (int v = 0; v < 2; v++) t.off[v] = (unsigned)(((tid >> 5) + 8 * v) * (int)ld + (tid & 31) * 4) * 4u;
     }
+    return t;
+}
+
+// 16-byte loads of half h of the tile whose reduction range starts at r0 (needs 16-byte aligned rows
+// and a full 32-deep tile; an RS tile must not run past the row's leading dimension)
+template <bool RC>
+__device__ inline void load_half_vec(const TileAddr<RC> &t, int r0, int h, f32x4 &x0, f32x4 &x1) {
+    const char *o = reinterpret_cast<const char *>(RC ? t.origin + r0 + 16 * h : t.origin + (int64_t)(r0 + 16 * h) * t.ld);
+    x0 = *reinterpret_cast<const f32x4 *>(o + t.off[0]);
+    x1 = *reinterpret_cast<const f32x4 *>(o + t.off[1]);
+}
+
+// any shape / alignment: 4-byte loads from clamped addresses, zero beyond the operand's extent
+template <bool RC>
+__device__ inline void load_half_scalar(const TileAddr<RC> &t, int r0, int r_end, int h, f32x4 &x0, f32x4 &x1) {
+    const int tid = threadIdx.x;
+    const float *base = RC ? t.origin - (int64_t)t.o0 * t.ld : t.origin - t.o0;
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+        int o, r;
+        if constexpr (RC) { o = t.o0 + (tid >> 2) + 64 * v; r = r0 + 16 * h + (tid & 3) * 4; }
+        else { r = r0 + 16 * h + (tid >> 5) + 8 * v; o = t.o0 + (tid & 31) * 4; }
+        f32x4 x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int oo = RC ? o : o + q, rr = RC ? r + q : r;
+            const bool ok = oo < t.o_end && rr < r_end;
+            const int oc = oo < t.o_end ? oo : t.o_end - 1, rc = rr < r_end ? rr : r_end - 1;
+            const float e = RC ? base[(int64_t)oc * t.ld + rc] : base[(int64_t)rc * t.ld + oc];
+            x[q] = ok ? e : 0.f;
+        }
+        if (v == 0) x0 = x; else x1 = x;
+    }
+}
+
+// a pair of float32 -> the pair's three bf16 pieces (each packed in one dword), 9 VALU operations
+__device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &l) {
+    const bf16x2 hb = __builtin_convertvector(x, bf16x2);
+    h = __builtin_bit_cast(unsigned, hb);
+    const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+    const f32x2 r1 = x - hf;
+    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+    m = __builtin_bit_cast(unsigned, mb);
+    const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;
+    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+    l = __builtin_bit_cast(unsigned, lb);
 }
 
 __device__ inline int rs_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch of row `row`
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+// split the two registers of one half-step and write the pieces to the three planes at `planes`
 template <bool RC>
-__device__ inline void store_planes(unsigned char *__restrict__ planes, const float4 (&reg)[4]) {
+__device__ inline void split_store_half(unsigned char *__restrict__ planes, const f32x4 &v0, const f32x4 &v1) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int v = 0; v < 2; v++) {
+        const f32x4 x = v ? v1 : v0;
         int off;
-        if constexpr (RC) off = ((tid >> 3) + 32 * u) * kRcRowBytes + (tid & 7) * 8;
-        else off = rs_chunk_off((tid >> 5) + 8 * u, (tid & 31) >> 1) + 8 * (tid & 1);
-        bf16x4 h, m, l;
-        split3(reg[u], h, m, l);
-        *reinterpret_cast<bf16x4 *>(planes + off) = h;
-        *reinterpret_cast<bf16x4 *>(planes + kPlaneBytes + off) = m;
-        *reinterpret_cast<bf16x4 *>(planes + 2 * kPlaneBytes + off) = l;
+        if constexpr (RC) off = rc_chunk_off((tid >> 2) + 64 * v, (tid & 3) >> 1) + 8 * (tid & 1);
+        else off = rs_chunk_off((tid >> 5) + 8 * v, (tid & 31) >> 1) + 8 * (tid & 1);
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pair(f32x2{x[0], x[1]}, h0, m0, l0);
+        split3_pair(f32x2{x[2], x[3]}, h1, m1, l1);
+        *reinterpret_cast<u32x2 *>(planes + off) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(planes + kPlane16 + off) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2 *>(planes + 2 * kPlane16 + off) = u32x2{l0, l1};
     }
 }
 
-// 8 consecutive reduction elements (16-deep chunk kc, lane half h takes 8h..8h+7) of output index
-// o_base + (lane & 31), from one plane
+// 8 consecutive reduction elements (lane half h takes 8h..8h+7 of the 16-deep half-step) of output
+// index o_base + (lane & 31), from one plane
 template <bool RC>
-__device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, int o_base, int kc) {
+__device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, int o_base) {
     const int lane = threadIdx.x & 63;
     if constexpr (RC) {
-        return *reinterpret_cast<const bf16x8 *>(plane + (o_base + (lane & 31)) * kRcRowBytes + kc * 32 + (lane >> 5) * 16);
+        return *reinterpret_cast<const bf16x8 *>(plane + rc_chunk_off(o_base + (lane & 31), lane >> 5));
     } else {
         // per 16-lane group the transposing read takes a 4-row x 16-column block; lane 4q+p of the
         // group supplies the address of row q, columns 4p..4p+3, and lane i receives column i
         const int li = lane & 15, g = lane >> 4, h = g >> 1;
         const int q = li >> 2, pp = li & 3;
         const int ch = (o_base >> 3) + 2 * (g & 1) + (pp >> 1);
-        const int row0 = kc * 16 + 8 * h + q;
+        const int row0 = 8 * h + q;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (lds_s16x4 *)(plane + rs_chunk_off(row0, ch) + 8 * (pp & 1)));
@@ -400,49 +487,70 @@ __device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, in
     }
 }
 
-// Compiler fence for register values: uses of `reg` after this point cannot be moved above it.
-// Keeps the bf16 split of a prefetched tile behind the MFMA block (it is plain arithmetic on the
-// loaded registers, which the compiler would otherwise start as soon as the loads are issued,
-// waiting for them with the whole MFMA block still to come).
-__device__ inline void pin_here(float4 (&reg)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; u++) asm volatile("" : "+v"(reg[u].x), "+v"(reg[u].y), "+v"(reg[u].z), "+v"(reg[u].w));
-}
+// Compiler fence for register values: uses of the registers after this point cannot be moved above
+// it.  Keeps the bf16 split of a prefetched tile in the half-step it belongs to (it is plain
+// arithmetic on loaded registers, which the compiler would otherwise start right behind the loads,
+// waiting for them with whole MFMA blocks still to come).
+__device__ inline void pin_here(f32x4 &a, f32x4 &b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
-// 48 MFMAs: one 32-deep reduction step of the wave's 64x64 output
+// the 12 fragments of one 16-deep half-step of the wave's 64x64 output, out of one stage
+struct Frags {
+    bf16x8 a[2][3], b[2][3];
+};
+
 template <bool A_RC, bool B_RC>
-__device__ inline void mfma_step_bf16x3(const unsigned char *__restrict__ pa, const unsigned char *__restrict__ pb, int wr,
-                                        int wc, f32x16 (&acc)[2][2]) {
+__device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags &f) {
+    const unsigned char *pa = stage, *pb = stage + 3 * kPlane16;
 #pragma unroll
-    for (int kc = 0; kc < 2; kc++) {
-        bf16x8 a[2][3], b[2][3];
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
-#pragma unroll
-            for (int mi = 0; mi < 2; mi++) a[mi][pl] = load_frag16<A_RC>(pa + pl * kPlaneBytes, wr * 64 + mi * 32, kc);
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++) b[ni][pl] = load_frag16<B_RC>(pb + pl * kPlaneBytes, wc * 64 + ni * 32, kc);
+            f.a[i][pl] = load_frag16<A_RC>(pa + pl * kPlane16, wr * 64 + i * 32);
+            f.b[i][pl] = load_frag16<B_RC>(pb + pl * kPlane16, wc * 64 + i * 32);
         }
+}
+
+// 24 MFMAs: six cross terms for each of the four 32x32 accumulators, smallest terms first
+__device__ inline void mfma_frags(const Frags &f, f32x16 (&acc)[2][2]) {
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+    for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) {
-                f32x16 c = acc[mi][ni];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
-                acc[mi][ni] = c;
-            }
+        for (int ni = 0; ni < 2; ni++) {
+            f32x16 c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][2], f.b[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][1], f.b[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][1], f.b[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][0], c, 0, 0, 0);
+            acc[mi][ni] = c;
+        }
+}
+
+template <bool A_RC, bool B_RC>
+__device__ inline void mfma_half(const unsigned char *__restrict__ stage, int wr, int wc, f32x16 (&acc)[2][2]) {
+    Frags f;
+    load_frags<A_RC, B_RC>(stage, wr, wc, f);
+    mfma_frags(f, acc);
+}
+
+// Scheduling recipe for one half-step region (12 fragment reads, 24 MFMAs, the split of 16 elements
+// per lane and its 6 LDS writes): all reads first, then three split operations behind every MFMA,
+// the writes of an operand once its pieces are complete.
+__device__ inline void interleave_half() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (i == 11 || i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
     }
 }
 
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * kPlaneBytes];
-    unsigned char *pa = smem, *pb = smem + 3 * kPlaneBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage16];
+    unsigned char *const s0 = smem, *const s1 = smem + kStage16;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -471,71 +579,88 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     // bias gradient (weight-gradient product only): this thread's four output rows of the A tile,
     // summed over every staged reduction row
     const bool do_colsum = !A_RC && p.colsum != nullptr && bx == 0;
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto add_colsum = [&](const float4 (&ra)[4]) {
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    // split half-step h of a raw tile pair into `stage` (`live` false: the registers hold no new
+    // tile and the stage is never read; only the bias-gradient sum must skip them)
+    auto stage_half = [&](unsigned char *stage, f32x4 (&xa)[4], f32x4 (&xb)[4], int h, bool live) {
         if constexpr (!A_RC) {
             if (do_colsum) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) { cs.x += ra[u].x; cs.y += ra[u].y; cs.z += ra[u].z; cs.w += ra[u].w; }
+                const f32x4 add = xa[2 * h] + xa[2 * h + 1];
+                cs += live ? add : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        split_store_half<A_RC>(stage, xa[2 * h], xa[2 * h + 1]);
+        split_store_half<B_RC>(stage + 3 * kPlane16, xb[2 * h], xb[2 * h + 1]);
     };
 
-    float4 ra[4], rb[4];
-    if (steps > 0) {
-        if (vec_tile && full_steps > 0) {
-            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, k_begin, ra);
-            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, k_begin, rb);
-        } else {
-            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra);
-            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb);
-        }
-        add_colsum(ra);
-        store_planes<A_RC>(pa, ra);
-        store_planes<B_RC>(pb, rb);
-    }
-    __syncthreads();
-
-    int st = 0;
-    if (vec_tile) {
-        for (; st + 1 < full_steps; st++) {
-            const int r0 = k_begin + (st + 1) * BK;
-            load_tile_vec<A_RC>(p.A, p.lda, m0, p.M, r0, ra);
-            load_tile_vec<B_RC>(p.B, p.ldb, n0, p.N, r0, rb);
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMA block
-            mfma_step_bf16x3<A_RC, B_RC>(pa, pb, wr, wc, acc);
+    // Tiles [t_begin, t_end) of the reduction through the two-stage pipeline.  VEC: 16-byte loads
+    // (full 32-deep tiles of aligned operands), else clamped 4-byte loads with zero fill.
+    const TileAddr<A_RC> ta = make_tile_addr<A_RC>(p.A, p.lda, m0, p.M);
+    const TileAddr<B_RC> tb = make_tile_addr<B_RC>(p.B, p.ldb, n0, p.N);
+    f32x4 xa[4], xb[4], ya[4], yb[4];
+    auto run = [&](auto vec_tag, int t_begin, int t_end) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        // request half h of tile tt (clamped: surplus requests re-read the last tile)
+        auto load = [&](int tt, int h, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
+            const int tc = tt < t_end ? tt : t_end - 1;
+            const int r0 = k_begin + tc * BK;
+            if constexpr (VEC) {
+                load_half_vec<A_RC>(ta, r0, h, ra[2 * h], ra[2 * h + 1]);
+                load_half_vec<B_RC>(tb, r0, h, rb[2 * h], rb[2 * h + 1]);
+            } else {
+                load_half_scalar<A_RC>(ta, r0, k_end, h, ra[2 * h], ra[2 * h + 1]);
+                load_half_scalar<B_RC>(tb, r0, k_end, h, rb[2 * h], rb[2 * h + 1]);
+            }
+        };
+        // One tile = two half-steps.  On entry stage 0 holds half 0 of tile tt, (ua, ub) hold the raw
+        // tile tt and (va, vb) half 0 of tile tt+1 (in flight or landed).  Every half-step requests the
+        // half tile that is staged two half-steps later, into the registers staged one half-step ago.
+        auto tile_step = [&](int tt, f32x4 (&ua)[4], f32x4 (&ub)[4], f32x4 (&va)[4], f32x4 (&vb)[4]) {
+            Frags f;
+            load(tt + 1, 1, va, vb);
+            __builtin_amdgcn_sched_barrier(0);   // the requests go out ahead of the MFMA block
+            load_frags<A_RC, B_RC>(s0, wr, wc, f);   // reads first: the writes below go to the other stage
+            pin_here(ua[2], ua[3]);
+            pin_here(ub[2], ub[3]);
+            stage_half(s1, ua, ub, 1, true);
+            mfma_frags(f, acc);
+            interleave_half();
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                    // every wave is done reading the planes
-            pin_here(ra);
-            pin_here(rb);
-            add_colsum(ra);
-            store_planes<A_RC>(pa, ra);
-            store_planes<B_RC>(pb, rb);
             __syncthreads();
-        }
-    }
-    for (; st < steps; st++) {
-        const bool more = st + 1 < steps;
-        if (more) {
-            const int r0 = k_begin + (st + 1) * BK;
-            load_tile_scalar<A_RC>(p.A, p.lda, m0, p.M, r0, k_end, ra);
-            load_tile_scalar<B_RC>(p.B, p.ldb, n0, p.N, r0, k_end, rb);
-        }
-        mfma_step_bf16x3<A_RC, B_RC>(pa, pb, wr, wc, acc);
+            load(tt + 2, 0, ua, ub);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags<A_RC, B_RC>(s1, wr, wc, f);
+            pin_here(va[0], va[1]);
+            pin_here(vb[0], vb[1]);
+            stage_half(s0, va, vb, 0, tt + 1 < t_end);
+            mfma_frags(f, acc);
+            interleave_half();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        load(t_begin, 0, xa, xb);
+        load(t_begin, 1, xa, xb);
+        load(t_begin + 1, 0, ya, yb);
+        stage_half(s0, xa, xb, 0, true);
         __syncthreads();
-        if (more) {
-            add_colsum(ra);
-            store_planes<A_RC>(pa, ra);
-            store_planes<B_RC>(pb, rb);
+        for (int t = t_begin; t < t_end; t += 2) {
+            tile_step(t, xa, xb, ya, yb);
+            if (t + 1 >= t_end) break;
+            tile_step(t + 1, ya, yb, xa, xb);
         }
-        __syncthreads();
+    };
+    int t_done = 0;
+    if (vec_tile && full_steps > 0) {
+        run(std::true_type{}, 0, full_steps);
+        t_done = full_steps;
     }
+    if (t_done < steps) run(std::false_type{}, t_done, steps);   // edge tiles, unaligned operands, partial last tile
 
     float *fsm = reinterpret_cast<float *>(smem);
     if constexpr (!A_RC) {
         if (do_colsum) {
             // thread (tid>>5, tid&31) holds the sums of output rows 4*(tid&31).. over its reduction rows
-            *reinterpret_cast<float4 *>(fsm + (tid >> 5) * BM + (tid & 31) * 4) = cs;
+            *reinterpret_cast<f32x4 *>(fsm + (tid >> 5) * BM + (tid & 31) * 4) = cs;
             __syncthreads();
             if (tid < BM && m0 + tid < p.M) {
                 float a = 0.f;
