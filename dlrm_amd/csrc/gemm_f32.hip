@@ -398,9 +398,14 @@ __device__ inline TileAddr<RC> make_tile_addr(const float *base, int64_t ld, int
 // and a full 32-deep tile; an RS tile must not run past the row's leading dimension)
 template <bool RC>
 __device__ inline void load_half_vec(const TileAddr<RC> &t, int r0, int h, f32x4 &x0, f32x4 &x1) {
-    const char *o = reinterpret_cast<const char *>(RC ? t.origin + r0 + 16 * h : t.origin + (int64_t)(r0 + 16 * h) * t.ld);
-    x0 = *reinterpret_cast<const f32x4 *>(o + t.off[0]);
-    x1 = *reinterpret_cast<const f32x4 *>(o + t.off[1]);
+    // buffer loads: the wave-uniform half-tile origin travels in a scalar resource descriptor and each
+    // piece costs one 32-bit offset register (no range check is wanted: the record count is the maximum)
+    const float *o = RC ? t.origin + r0 + 16 * h : t.origin + (int64_t)(r0 + 16 * h) * t.ld;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(o), 0, 0xffffffff, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    x0 = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)t.off[0], 0, 0));
+    x1 = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)t.off[1], 0, 0));
 }
 
 // any shape / alignment: 4-byte loads from clamped addresses, zero beyond the operand's extent
@@ -674,15 +679,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     store_output(p, acc, fsm, m0, n0, bz);
 }
 
-// out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out)
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, int64_t stride, int rows, int cols,
-                                    float *__restrict__ out, int64_t ld_out) {
+// out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out).  A 256-thread workgroup owns
+// 64 consecutive outputs; thread (q, e) adds the slabs s = q, q+4, ... of output e with eight loads in
+// flight, and the four partial sums meet in LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, int64_t stride,
+                                                           int rows, int cols, float *__restrict__ out,
+                                                           int64_t ld_out) {
+    __shared__ float part[4][64];
     const int64_t n = (int64_t)rows * cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + e;
         float a = 0.f;
-        for (int s = 0; s < splits; s++) a += slabs[(int64_t)s * stride + i];
-        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-        out[(int64_t)r * ld_out + c] = a;
+        if (i < n) {
+            int s = q;
+            for (; s + 28 < splits; s += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
+#pragma unroll
+                for (int u = 0; u < 8; u++) a += v[u];
+            }
+            for (; s < splits; s += 4) a += slabs[(int64_t)s * stride + i];
+        }
+        part[q][e] = a;
+        __syncthreads();
+        if (q == 0 && i < n) {
+            const float t = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+            const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+            out[(int64_t)r * ld_out + c] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -725,7 +752,7 @@ static int choose_splits(int M_red, int tiles) {
     if (max_by_depth < 1) max_by_depth = 1;
     int s = want < max_by_depth ? want : max_by_depth;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;
     return s;
 }
 
@@ -812,12 +839,12 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
         const int real_splits = (int)ceil_div(l->M, p.k_per_split);
         if (int rc = launch_gemm<false, false>(p, real_splits, s)) return rc;
         const int64_t n = (int64_t)l->N * l->K;
-        const unsigned blocks = (unsigned)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
+        const unsigned blocks = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, real_splits, p.slab_stride,
                            l->N, l->K, l->d_dw, l->dw_ld);
         DLRM_LAUNCH_CHECK();
         if (l->d_db) {
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 256)), dim3(256), 0, s, db_partial,
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 64)), dim3(256), 0, s, db_partial,
                                real_splits, (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
             DLRM_LAUNCH_CHECK();
         }
