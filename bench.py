@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--row-cap", type=int, default=0, help="cap rows per table (debug on small boxes); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", default="table", choices=["table", "hybrid"],
+                    help="N>1: whole tables per rank, or the biggest tables split by rows over all ranks")
+    ap.add_argument("--row-wise-min-rows", type=int, default=20_000_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,8 +160,12 @@ def main():
     B = Bg // world
     model_ref = {"unique_rows": 0}
     timer = install_timers(ops, model_ref)
-    model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg)
-    local_rows = [cfg.table_rows[t] for t in model.my_tables]
+    plan = None
+    if args.sharding == "hybrid" and world > 1:
+        from dlrm_amd.sharding import plan_hybrid
+        plan = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows)
+    model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan)
+    local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled
     n_batches = 4
@@ -166,7 +173,7 @@ def main():
     for i in range(n_batches):
         dense, idx, off, labels = synthetic_batch(local_rows, Bg, cfg.lookups, cfg.dense_in, dev,
                                                   seed=1000 * (i + 1) + rank, loss=cfg.loss, dist=args.dist,
-                                                  local_batch=B)
+                                                  local_batch=B, shared_from=model.Tl, shared_seed=77 * (i + 1))
         # unique rows touched per batch (for the algorithmic bytes of the sparse update)
         uniq = 0
         n_per = Bg * cfg.lookups
@@ -246,7 +253,9 @@ def main():
                        "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
                        "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
-                       "parallelism": "single GPU" if world == 1 else "table-wise x%d + data-parallel MLP" % world},
+                       "parallelism": "single GPU" if world == 1 else
+                       ("%s x%d + data-parallel MLP" % ("table-wise" if not model.Trw else
+                                                        "table-wise + %d row-wise tables" % model.Trw, world))},
             "loss": float(loss.item()),
             "roofline": roofline,
             "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,

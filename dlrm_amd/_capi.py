@@ -37,6 +37,7 @@ class EmbBagDesc(C.Structure):
         ("include_last_offset", C.c_int32),
         ("pooling", C.c_int32),
         ("d_error_flag", C.c_void_p),
+        ("d_shard_row_begin", C.c_void_p),
     ]
 
 

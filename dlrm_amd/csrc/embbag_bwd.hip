@@ -88,6 +88,7 @@ struct BwdParams {
     float lr;
     float eps;
     float *state;
+    const int64_t *shard;  // first global row held per table (row-wise shard), or NULL
 };
 
 // lanes_per_bag lanes walk the positions of one bag
@@ -105,13 +106,14 @@ __global__ __launch_bounds__(kBwdThreads) void expand_pairs_kernel(BwdParams p, 
     const int t = (int)((uint32_t)g / (uint32_t)p.B);
     const int64_t tbase = p.tro ? p.tro[t] : 0;
     const int64_t trows = p.tro ? p.tro[t + 1] - tbase : p.total_rows;
+    const int64_t sbase = p.shard ? p.shard[t] : 0;
     bool bad = false;
     for (int64_t q = start + lane; q < end; q += lanes_per_bag) {
-        const int64_t r = (int64_t)idx[q];
+        const int64_t r = (int64_t)idx[q] - sbase;
         KEY k;
         if (r < 0 || r >= trows) {
             k = (KEY)p.total_rows;  // sorts behind every real row and is skipped by the update
-            bad = true;
+            bad = bad || p.shard == nullptr;   // rows of another shard are not an error
         } else {
             k = (KEY)(tbase + r);
         }
@@ -575,7 +577,7 @@ extern "C" int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_
     p.T = e->num_tables; p.D = e->dim; p.idx = e->d_indices; p.off = e->d_offsets;
     p.n_idx = e->n_indices; p.B = e->batch; p.n_bags = n_bags;
     p.include_last = e->include_last_offset; p.mean = e->pooling == DLRM_POOL_MEAN;
-    p.grad = d_grad; p.grad_ld = grad_ld; p.err = e->d_error_flag;
+    p.grad = d_grad; p.grad_ld = grad_ld; p.err = e->d_error_flag; p.shard = e->d_shard_row_begin;
     p.last_wins = opt->dup_mode == DLRM_DUP_LAST_WINS;
     p.adagrad = opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE;
     p.lr = opt->lr; p.eps = opt->eps; p.state = opt->d_opt_state;

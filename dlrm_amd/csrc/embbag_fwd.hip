@@ -40,6 +40,7 @@ struct FwdParams {
     int64_t out_ld;
     int *err;
     int bpg;  // bags per group (group kernel)
+    const int64_t *shard;  // first global row held per table (row-wise shard), or NULL
 };
 
 // 16 bytes of a row as NF floats
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
     int64_t look_next_table = p.B - b_cur;  // local bag index at which the next table starts
     int64_t tbase = p.tro ? p.tro[t_look] : 0;
     int64_t trows = p.tro ? p.tro[t_look + 1] - tbase : p.total_rows;
+    int64_t sbase = p.shard ? p.shard[t_look] : 0;
 
     bool col_ok[NC];
     int col[NC];
@@ -184,12 +186,13 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
                     look_next_table += p.B;
                     tbase = p.tro[t_look];
                     trows = p.tro[t_look + 1] - tbase;
+                    if (p.shard) sbase = p.shard[t_look];
                 }
                 bagj[j] = look;
-                const int64_t r = (int64_t)idx[pj];
+                const int64_t r = (int64_t)idx[pj] - sbase;
                 if (r < 0 || r >= trows) {
                     ok[j] = false;
-                    bad = true;
+                    bad = bad || p.shard == nullptr;
                 } else {
                     const int64_t e0 = (tbase + r) * p.D;
 #pragma unroll
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_wave_kernel(FwdParams 
     const int64_t b = g - (int64_t)t * p.B;
     const int64_t tbase = p.tro ? p.tro[t] : 0;
     const int64_t trows = p.tro ? p.tro[t + 1] - tbase : p.total_rows;
+    const int64_t sbase = p.shard ? p.shard[t] : 0;
     const int64_t start = s_off[wave], end = s_off[wave + 1];
 
     bool col_ok[NC];
@@ -268,10 +272,10 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_wave_kernel(FwdParams 
             const int64_t pj = pos + (int64_t)j * NG;
             ok[j] = pj < end;
             if (ok[j]) {
-                const int64_t r = (int64_t)idx[pj];
+                const int64_t r = (int64_t)idx[pj] - sbase;
                 if (r < 0 || r >= trows) {
                     ok[j] = false;
-                    bad = true;
+                    bad = bad || p.shard == nullptr;
                 } else {
                     const int64_t e0 = (tbase + r) * p.D;
 #pragma unroll
@@ -373,7 +377,7 @@ extern "C" int dlrm_embbag_forward(const dlrm_embbag *e, float *d_out, int64_t o
     p.T = e->num_tables; p.D = e->dim; p.idx = e->d_indices; p.off = e->d_offsets;
     p.n_idx = e->n_indices; p.B = e->batch; p.n_bags = n_bags;
     p.include_last = e->include_last_offset; p.mean = e->pooling == DLRM_POOL_MEAN;
-    p.out = d_out; p.out_ld = out_ld; p.err = e->d_error_flag;
+    p.out = d_out; p.out_ld = out_ld; p.err = e->d_error_flag; p.shard = e->d_shard_row_begin;
 
     const int esz = e->row_dtype == DLRM_F32 ? 4 : 2;
     const int nf = 16 / esz;

@@ -20,10 +20,13 @@ def zipf_ids(n, rows, alpha, gen, device):
 
 
 def synthetic_batch(table_rows, batch, lookups, dense_in, device, seed, loss="bce", dist="uniform", alpha=1.05,
-                    idx_dtype=torch.int32, local_batch=None):
+                    idx_dtype=torch.int32, local_batch=None, shared_from=None, shared_seed=0):
     """Returns (dense [local_batch, dense_in], indices [T*batch*lookups], offsets [T*batch+1], labels).
-    Bags are table-major (g = t*batch + b), fixed `lookups` rows per bag."""
+    Bags are table-major (g = t*batch + b), fixed `lookups` rows per bag.  Tables shared_from..
+    draw their ids from a generator seeded with `shared_seed` only: row-wise split tables must see
+    the same global batch on every rank."""
     gen = torch.Generator(device=device).manual_seed(seed)
+    gen_shared = torch.Generator(device=device).manual_seed(shared_seed)
     T = len(table_rows)
     lb = batch if local_batch is None else local_batch
     dense = torch.randn((lb, dense_in), generator=gen, device=device)
@@ -34,10 +37,11 @@ def synthetic_batch(table_rows, batch, lookups, dense_in, device, seed, loss="bc
     n_per = batch * lookups
     idx = torch.empty(T * n_per, dtype=idx_dtype, device=device)
     for t, rows in enumerate(table_rows):
+        g = gen_shared if shared_from is not None and t >= shared_from else gen
         if dist == "zipf":
-            v = zipf_ids(n_per, rows, alpha, gen, device)
+            v = zipf_ids(n_per, rows, alpha, g, device)
         else:
-            v = torch.randint(0, rows, (n_per,), generator=gen, device=device, dtype=torch.int64)
+            v = torch.randint(0, rows, (n_per,), generator=g, device=device, dtype=torch.int64)
         idx[t * n_per:(t + 1) * n_per] = v.to(idx_dtype)
     off = (torch.arange(T * batch + 1, device=device, dtype=torch.int64) * lookups).to(idx_dtype)
     return dense, idx, off, labels

@@ -8,10 +8,13 @@ Everything numeric runs in the HIP kernels of libdlrm_amd.so through the C ABI
 (dlrm_amd.ops); torch provides device buffers, streams and, when the model is
 sharded, the RCCL collectives (torch.distributed, backend "nccl").
 
-Sharding (world > 1): every rank owns whole tables (sharding.plan_table_wise)
-and looks them up for the GLOBAL batch; pooled vectors go to the rank that owns
-each batch slice with one all-to-all, their gradients come back with another;
-the MLPs are data parallel and their gradients are summed with one all-reduce
+Sharding (world > 1): every rank looks its tables up for the GLOBAL batch.
+Whole tables (sharding.plan_table_wise): pooled vectors go to the rank that owns
+each batch slice with one all-to-all, their gradients come back with another.
+Row-wise split tables (sharding.plan_hybrid): every rank pools the rows of its
+range, a reduce-scatter over the batch adds the partial sums, an all-gather
+brings the gradients of the global batch back and every rank updates its rows.
+The MLPs are data parallel and their gradients are summed with one all-reduce
 of a single flat buffer.  Losses are means over the global batch, so per-rank
 gradients simply add.
 """
@@ -176,8 +179,15 @@ class DLRM:
         self.Bg = batch * world
         self.dev = torch.device(device)
         self.plan = plan or plan_table_wise(cfg.table_rows, world, cfg.dim, 2 if cfg.row_dtype == "bf16" else 4)
-        self.my_tables = self.plan.local_tables(rank)
-        self.Tl = len(self.my_tables)
+        if world == 1:
+            # one rank holds everything whole, in the plan's feature order
+            self.my_tables, self.rw_tables = list(self.plan.feature_order), []
+        else:
+            self.my_tables, self.rw_tables = self.plan.local_tables(rank), list(self.plan.row_wise)
+        self.Tl = len(self.my_tables)          # whole tables of this rank
+        self.Trw = len(self.rw_tables)         # tables of which this rank holds a row range
+        # tables in the order this rank's indices / offsets must list them
+        self.local_table_ids = list(self.my_tables) + list(self.rw_tables)
         T, D, F = cfg.num_tables, cfg.dim, cfg.num_features
         dev = self.dev
         self.pooling = _capi.POOL_MEAN if cfg.pooling == "mean" else _capi.POOL_SUM
@@ -185,7 +195,10 @@ class DLRM:
             raise ValueError("dot interaction needs bottom[-1] == dim")
 
         # ---- embedding tables of this rank, one allocation, table-major
-        rows = [cfg.table_rows[t] for t in self.my_tables]
+        ranges = [(0, cfg.table_rows[t]) for t in self.my_tables] + \
+                 [self.plan.row_range(t, rank) for t in self.rw_tables]
+        rows = [hi - lo for lo, hi in ranges]
+        self.local_rows = rows
         tro = [0]
         for r in rows:
             tro.append(tro[-1] + r)
@@ -196,8 +209,9 @@ class DLRM:
         if init_tables and self.total_rows:
             # every table is its own stream of uniform [0,1) values, keyed by the GLOBAL
             # table id, so a sharded model holds the same numbers as a single-GPU one
-            for lt, t in enumerate(self.my_tables):
-                ops.table_init_uniform_(self.weight[tro[lt]:tro[lt + 1]], seed=(seed << 20) + 7919 * (t + 1))
+            for lt, t in enumerate(self.local_table_ids):
+                ops.table_init_uniform_(self.weight[tro[lt]:tro[lt + 1]], seed=(seed << 20) + 7919 * (t + 1),
+                                        first=ranges[lt][0] * D)
         self.opt_state = None
         if cfg.emb_optimizer == "adagrad":
             self.opt_state = torch.zeros(max(self.total_rows, 1), dtype=torch.float32, device=dev)
@@ -250,16 +264,40 @@ class DLRM:
             self.send_splits = [B * self.Tl * D] * world
             self.recv_splits = [B * len(self.plan.tables_of_rank[j]) * D for j in range(world)]
             self.a2a_send = torch.zeros(max(self.Bg * self.Tl * D, 1), **f32)   # [Bg, Tl*D]
-            self.a2a_recv = torch.zeros(max(B * T * D, 1), **f32)               # blocks [B, Tj*D], j = 0..W-1
-            self.g_send = torch.zeros(max(B * T * D, 1), **f32)
+            n_tw = self.plan.n_table_wise
+            self.a2a_recv = torch.zeros(max(B * n_tw * D, 1), **f32)            # blocks [B, Tj*D], j = 0..W-1
+            self.g_send = torch.zeros(max(B * n_tw * D, 1), **f32)
             self.g_recv = torch.zeros(max(self.Bg * self.Tl * D, 1), **f32)
+            if self.Trw:
+                self.shard_row_begin = torch.tensor([lo for lo, _ in ranges[self.Tl:]], dtype=torch.int64, device=dev)
+                self.rw_part = torch.zeros((self.Bg, self.Trw * D), **f32)   # partial sums / gathered gradients
+                self.rw_local = torch.zeros((B, self.Trw * D), **f32)       # this rank's batch slice
 
     # ------------------------------------------------------------ embeddings
 
     def _emb_kwargs(self, indices, offsets):
-        return dict(weight=self.weight, indices=indices, offsets=offsets, batch=self.Bg, num_tables=self.Tl,
-                    table_row_offsets=self.table_row_offsets, pooling=self.pooling, include_last_offset=True,
-                    error_flag=self.err_flag)
+        """Descriptor arguments for the whole tables of this rank: the first Tl tables of the
+        local order (offsets are table-major and absolute, so a prefix is a valid CSR)."""
+        n = self.Tl * self.Bg
+        return dict(weight=self.weight, indices=indices, offsets=offsets[:n + 1], batch=self.Bg, num_tables=self.Tl,
+                    table_row_offsets=self.table_row_offsets[:self.Tl + 1], pooling=self.pooling,
+                    include_last_offset=True, error_flag=self.err_flag)
+
+    def _rw_kwargs(self, indices, offsets):
+        """Same for the row ranges this rank holds of the row-wise tables."""
+        n = self.Tl * self.Bg
+        return dict(weight=self.weight, indices=indices, offsets=offsets[n:], batch=self.Bg, num_tables=self.Trw,
+                    table_row_offsets=self.table_row_offsets[self.Tl:], pooling=self.pooling,
+                    include_last_offset=True, error_flag=self.err_flag, shard_row_begin=self.shard_row_begin)
+
+    def _reduce_scatter_batch(self, out, inp):
+        """out [B, C] = sum over ranks of their inp [Bg, C] rows of this rank's batch slice."""
+        import torch.distributed as dist
+        if dist.get_backend(self.pg) == "gloo":       # no reduce-scatter there: CPU rehearsal only
+            dist.all_reduce(inp, group=self.pg)
+            out.copy_(inp[self.rank * self.B:(self.rank + 1) * self.B])
+        else:
+            dist.reduce_scatter_tensor(out, inp, group=self.pg)
 
     def embedding_forward(self, indices, offsets):
         """emb::forward (src/dlrmtest.cpp:170-206) for this rank's tables over the
@@ -273,7 +311,9 @@ class DLRM:
         import torch.distributed as dist
         if self.Tl:
             ops.embbag_forward(out=self.a2a_send, out_ld=self.Tl * D, **self._emb_kwargs(indices, offsets))
-        dist.all_to_all_single(self.a2a_recv, self.a2a_send, self.recv_splits, self.send_splits, group=self.pg)
+        n_send, n_recv = self.Bg * self.Tl * D, B * self.plan.n_table_wise * D   # exact sizes (buffers hold >= 1 element)
+        dist.all_to_all_single(self.a2a_recv[:n_recv], self.a2a_send[:n_send], self.recv_splits, self.send_splits,
+                               group=self.pg)
         o = 0
         for j in range(self.world):
             first, cnt = self.plan.feature_slot(j)
@@ -282,6 +322,11 @@ class DLRM:
                 c0 = self.emb_col0 + first * D
                 ops.copy_2d_(self.feat[:, c0:c0 + cnt * D], blk)
             o += B * cnt * D
+        if self.Trw:
+            ops.embbag_forward(out=self.rw_part, out_ld=self.Trw * D, **self._rw_kwargs(indices, offsets))
+            self._reduce_scatter_batch(self.rw_local, self.rw_part)
+            c0 = self.emb_col0 + self.plan.n_table_wise * D
+            ops.copy_2d_(self.feat[:, c0:c0 + self.Trw * D], self.rw_local)
 
     def embedding_backward_update(self, indices, offsets):
         """autograd of embedding_bag + optimizer step + write-back
@@ -305,10 +350,19 @@ class DLRM:
                 c0 = self.emb_col0 + first * D
                 ops.copy_2d_(blk, self.dfeat[:, c0:c0 + cnt * D])
             o += B * cnt * D
-        dist.all_to_all_single(self.g_recv, self.g_send, self.send_splits, self.recv_splits, group=self.pg)
+        n_send, n_recv = self.Bg * self.Tl * D, B * self.plan.n_table_wise * D
+        dist.all_to_all_single(self.g_recv[:n_send], self.g_send[:n_recv], self.send_splits, self.recv_splits,
+                               group=self.pg)
         if self.Tl:
             self.ws_sparse = ops.embbag_backward_update(grad=self.g_recv, grad_ld=self.Tl * D,
                                                         **self._emb_kwargs(indices, offsets), **kw)
+        if self.Trw:
+            c0 = self.emb_col0 + self.plan.n_table_wise * D
+            ops.copy_2d_(self.rw_local, self.dfeat[:, c0:c0 + self.Trw * D])
+            dist.all_gather_into_tensor(self.rw_part, self.rw_local, group=self.pg)
+            kw["workspace"] = self.ws_sparse
+            self.ws_sparse = ops.embbag_backward_update(grad=self.rw_part, grad_ld=self.Trw * D,
+                                                        **self._rw_kwargs(indices, offsets), **kw)
 
     # ------------------------------------------------------------------ step
 

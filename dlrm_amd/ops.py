@@ -51,8 +51,8 @@ def table_init_uniform_(weight, seed, first=0):
 
 
 def make_embbag_desc(weight, indices, offsets, batch, num_tables=1, table_row_offsets=None,
-                     pooling=_capi.POOL_SUM, include_last_offset=False, error_flag=None):
-    _require_cuda(weight, indices, offsets, table_row_offsets, error_flag)
+                     pooling=_capi.POOL_SUM, include_last_offset=False, error_flag=None, shard_row_begin=None):
+    _require_cuda(weight, indices, offsets, table_row_offsets, error_flag, shard_row_begin)
     assert weight.dim() == 2 and weight.is_contiguous()
     assert indices.is_contiguous() and offsets.is_contiguous() and indices.dtype == offsets.dtype
     n_off = num_tables * batch + (1 if include_last_offset else 0)
@@ -75,15 +75,21 @@ def make_embbag_desc(weight, indices, offsets, batch, num_tables=1, table_row_of
     d.include_last_offset = int(include_last_offset)
     d.pooling = pooling
     d.d_error_flag = 0 if error_flag is None else error_flag.data_ptr()
+    if shard_row_begin is not None:
+        assert shard_row_begin.dtype == torch.int64 and shard_row_begin.numel() == num_tables
+        assert shard_row_begin.is_contiguous()
+    d.d_shard_row_begin = 0 if shard_row_begin is None else shard_row_begin.data_ptr()
     return d
 
 
 def embbag_forward(weight, indices, offsets, batch, num_tables=1, table_row_offsets=None,
                    pooling=_capi.POOL_SUM, include_last_offset=False, out=None, out_ld=None,
-                   error_flag=None):
-    """Pooled embeddings [batch, T*dim] (or written into `out` with row stride out_ld)."""
+                   error_flag=None, shard_row_begin=None):
+    """Pooled embeddings [batch, T*dim] (or written into `out` with row stride out_ld).
+    shard_row_begin (int64[T]): the tables are row-wise shards starting at these global rows;
+    indices stay global and those of other shards are skipped."""
     d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, pooling,
-                         include_last_offset, error_flag)
+                         include_last_offset, error_flag, shard_row_begin)
     if out is None:
         out_ld = num_tables * weight.shape[1]
         out = torch.empty((batch, out_ld), dtype=torch.float32, device=weight.device)
@@ -103,12 +109,12 @@ def embbag_backward_workspace_bytes(desc):
 def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, table_row_offsets=None,
                            pooling=_capi.POOL_SUM, include_last_offset=False, optimizer=_capi.OPT_SGD,
                            dup_mode=_capi.DUP_ACCUMULATE, lr=0.01, eps=1e-8, opt_state=None, grad_ld=None,
-                           workspace=None, error_flag=None):
+                           workspace=None, error_flag=None, shard_row_begin=None):
     """Sparse backward + fused row-wise SGD/Adagrad; updates `weight` (and
     `opt_state`) in place.  `grad` holds the pooled-vector gradients in the
     forward output layout.  Returns the workspace so it can be reused."""
     d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, pooling,
-                         include_last_offset, error_flag)
+                         include_last_offset, error_flag, shard_row_begin)
     _require_cuda(grad, opt_state, workspace)
     assert grad.dtype == torch.float32
     if grad_ld is None:

@@ -99,6 +99,13 @@ typedef struct dlrm_embbag {
     int32_t pooling;             /* DLRM_POOL_SUM | DLRM_POOL_MEAN */
     int32_t *d_error_flag;       /* optional device int32, set to 1 when an index is out of range */
                                  /* (such lookups are skipped); NULL = do not report */
+    const int64_t *d_shard_row_begin; /* optional device int64[T] for row-wise sharded tables: table t of */
+                                 /* this descriptor holds rows [begin[t], begin[t] + rows_t) of the full */
+                                 /* table; indices are global, those outside the range belong to another */
+                                 /* shard and are skipped without raising the error flag (mean pooling */
+                                 /* still divides by the full bag length, so shard outputs add up). */
+                                 /* NULL = tables are whole.  The reference stripes tables over parallel */
+                                 /* units by page (include/data2.h:150, src/emb_cache2.cpp:701-709). */
 } dlrm_embbag;
 
 /*

@@ -22,12 +22,42 @@ def table_init_uniform_(weight, seed, first=0):
     return weight
 
 
+def _shard_filter(indices, offsets, batch, num_tables, tro, shard_row_begin):
+    """Rows of a row-wise shard: drop the ids of other shards, re-base the rest.  Returns the
+    filtered CSR and the full bag lengths (mean pooling divides by those)."""
+    idx, off = _np(indices), _np(offsets)
+    tro = _np(tro) if tro is not None else None
+    beg = _np(shard_row_begin)
+    n_bags = num_tables * batch
+    ends = np.append(off[1:n_bags], off[n_bags] if len(off) > n_bags else len(idx)) if n_bags else np.zeros(0, off.dtype)
+    new_idx, new_off, lens = [], [0], []
+    for g in range(n_bags):
+        t = g // batch
+        rows_t = tro[t + 1] - tro[t]
+        seg = idx[off[g]:ends[g]] - beg[t]
+        keep = seg[(seg >= 0) & (seg < rows_t)]
+        new_idx.append(keep)
+        new_off.append(new_off[-1] + len(keep))
+        lens.append(ends[g] - off[g])
+    new_idx = np.concatenate(new_idx).astype(idx.dtype) if new_idx else np.zeros(0, idx.dtype)
+    return new_idx, np.asarray(new_off, dtype=off.dtype), np.asarray(lens, dtype=np.int64)
+
+
 def embbag_forward(weight, indices, offsets, batch, num_tables=1, table_row_offsets=None, pooling=0,
-                   include_last_offset=False, out=None, out_ld=None, error_flag=None):
+                   include_last_offset=False, out=None, out_ld=None, error_flag=None, shard_row_begin=None):
     D = weight.shape[1]
-    res = orc.embbag_forward(_np(weight), _np(indices), _np(offsets), batch, num_tables,
-                             None if table_row_offsets is None else _np(table_row_offsets), pooling,
-                             include_last_offset)
+    if shard_row_begin is not None:
+        assert include_last_offset
+        fi, fo, lens = _shard_filter(indices, offsets, batch, num_tables, table_row_offsets, shard_row_begin)
+        res = orc.embbag_forward(_np(weight), fi, fo, batch, num_tables, _np(table_row_offsets), 0, True)
+        if pooling == 1:
+            sc = np.where(lens > 0, 1.0 / np.maximum(lens, 1), 0.0).astype(np.float32)
+            res = (res.reshape(batch, num_tables, D) * sc.reshape(num_tables, batch).T[:, :, None]).reshape(batch, -1)
+            res = res.astype(np.float32)
+    else:
+        res = orc.embbag_forward(_np(weight), _np(indices), _np(offsets), batch, num_tables,
+                                 None if table_row_offsets is None else _np(table_row_offsets), pooling,
+                                 include_last_offset)
     flat = out.reshape(-1) if out.is_contiguous() else None
     if out.dim() == 2:
         out[:, :num_tables * D] = torch.from_numpy(res)
@@ -39,7 +69,7 @@ def embbag_forward(weight, indices, offsets, batch, num_tables=1, table_row_offs
 
 def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, table_row_offsets=None, pooling=0,
                            include_last_offset=False, optimizer=0, dup_mode=0, lr=0.01, eps=1e-8, opt_state=None,
-                           grad_ld=None, workspace=None, error_flag=None):
+                           grad_ld=None, workspace=None, error_flag=None, shard_row_begin=None):
     D = weight.shape[1]
     if grad.dim() == 1:
         g = torch.as_strided(grad, (batch, num_tables * D), (grad_ld, 1))
@@ -47,7 +77,18 @@ def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, 
         g = grad[:, :num_tables * D]
     w = _np(weight)
     st = None if opt_state is None else _np(opt_state)
-    orc.embbag_backward_update(w, _np(indices), _np(offsets), batch, np.ascontiguousarray(_np(g)), num_tables,
+    gn = np.ascontiguousarray(_np(g))
+    if shard_row_begin is not None:
+        assert include_last_offset
+        fi, fo, lens = _shard_filter(indices, offsets, batch, num_tables, table_row_offsets, shard_row_begin)
+        if pooling == 1:   # mean: the row gradient is grad / full bag length; feed it as a sum-pooled gradient
+            sc = np.where(lens > 0, 1.0 / np.maximum(lens, 1), 0.0).astype(np.float32)
+            gn = (gn.reshape(batch, num_tables, D) * sc.reshape(num_tables, batch).T[:, :, None]).reshape(batch, -1)
+            gn = np.ascontiguousarray(gn.astype(np.float32))
+        orc.embbag_backward_update(w, fi, fo, batch, gn, num_tables, _np(table_row_offsets), 0, True, optimizer,
+                                   dup_mode, lr, eps, st)
+        return workspace
+    orc.embbag_backward_update(w, _np(indices), _np(offsets), batch, gn, num_tables,
                                None if table_row_offsets is None else _np(table_row_offsets), pooling,
                                include_last_offset, optimizer, dup_mode, lr, eps, st)
     return workspace

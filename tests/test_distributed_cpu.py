@@ -1,6 +1,7 @@
-"""world_size 2 on CPU (gloo): the sharded train step of dlrm_amd.model -- table-wise plan,
-all-to-all of pooled vectors and of their gradients, all-reduce of the MLP gradients,
-global-mean loss -- must give what one process gives on the whole batch.  Compute is the CPU
+"""world_size 2 on CPU (gloo): the sharded train step of dlrm_amd.model -- table-wise plan
+(all-to-all of pooled vectors and of their gradients) and hybrid plan (plus row-wise split
+tables: reduce-scatter of partial sums, all-gather of gradients), all-reduce of the MLP
+gradients, global-mean loss -- must give what one process gives on the whole batch.  Compute is the CPU
 oracle patched in for dlrm_amd.ops (tests/cpu_ops_shim.py): this exercises the exchange layout
 and the reduction logic, which is the part no single-GPU test can see."""
 import os
@@ -12,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dlrm_amd.sharding import plan_table_wise
+from dlrm_amd.sharding import plan_hybrid, plan_table_wise
 
 
 def test_plan_table_wise_balances_and_is_deterministic():
@@ -35,6 +36,24 @@ def test_plan_table_wise_balances_and_is_deterministic():
     assert one.tables_of_rank == [[0, 1, 2]]
     many = plan_table_wise([5, 7], 4)            # more ranks than tables: some ranks own nothing
     assert sorted(len(r) for r in many.tables_of_rank) == [0, 0, 1, 1]
+
+
+def test_plan_hybrid_splits_big_tables_by_rows():
+    from dlrm_amd.model import MLPERF_TABLE_ROWS
+    p = plan_hybrid(MLPERF_TABLE_ROWS, 8, dim=128, row_wise_min_rows=20_000_000)
+    big = [t for t, r in enumerate(MLPERF_TABLE_ROWS) if r >= 20_000_000]
+    assert p.row_wise == big and len(big) == 5
+    for t in big:
+        rr = p.row_ranges[t]
+        assert rr[0][0] == 0 and rr[-1][1] == MLPERF_TABLE_ROWS[t]
+        assert all(rr[i][1] == rr[i + 1][0] for i in range(7))
+        assert max(hi - lo for lo, hi in rr) - min(hi - lo for lo, hi in rr) <= 1
+        assert p.owner[t] == -1
+    assert sorted(p.feature_order) == list(range(26)) and p.feature_order[-5:] == big
+    assert p.n_table_wise == 21
+    assert sorted(t for r in p.tables_of_rank for t in r) == [t for t in range(26) if t not in big]
+    with pytest.raises(ValueError):
+        plan_hybrid([3, 100], 4, row_wise_tables=[0])       # fewer rows than ranks
 
 
 def _free_port():
@@ -66,10 +85,16 @@ def _worker(rank, world, port, kind, ret):
         from oracle import oracle as orc
         from tests.oracle_model import make_batch, oracle_train_step
 
+        hybrid = kind.endswith("-rw")
+        kind = kind.split("-")[0]
         cfg = _cfg(kind)
         Bl = 6
         Bg = Bl * world
-        m = DLRM(cfg, Bl, device="cpu", rank=rank, world=world, seed=4)
+        plan = None
+        if hybrid:   # the two biggest tables are split by rows, the rest placed whole
+            plan = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=60 if kind == "dot" else 40)
+            assert len(plan.row_wise) == 2
+        m = DLRM(cfg, Bl, device="cpu", rank=rank, world=world, seed=4, plan=plan)
         if kind == "cat":
             for b in m.bottom.b + m.top.b:
                 b.abs_()
@@ -84,7 +109,7 @@ def _worker(rank, world, port, kind, ret):
             dense, idx, off, labels = make_batch(rng, cfg, Bg)
             L = cfg.lookups
             # this rank's tables over the global batch
-            my = m.my_tables
+            my = m.local_table_ids
             idx_l = np.concatenate([idx[t * Bg * L:(t + 1) * Bg * L] for t in my]) if my else np.zeros(0, np.int64)
             off_l = np.arange(len(my) * Bg + 1, dtype=np.int64) * L
             sl = slice(rank * Bl, (rank + 1) * Bl)
@@ -98,7 +123,8 @@ def _worker(rank, world, port, kind, ret):
             ok &= np.allclose(m.pred.numpy().reshape(-1), pred_ref[sl], rtol=1e-4, atol=1e-6)
             tro = m.table_row_offsets.numpy()
             for lt, t in enumerate(my):
-                ok &= np.allclose(m.weight[tro[lt]:tro[lt + 1]].numpy(), tables[t], rtol=1e-5, atol=1e-6)
+                lo, hi = (0, cfg.table_rows[t]) if lt < m.Tl else m.plan.row_range(t, rank)
+                ok &= np.allclose(m.weight[tro[lt]:tro[lt + 1]].numpy(), tables[t][lo:hi], rtol=1e-5, atol=1e-6)
             for a, r in zip(m.bottom.W + m.top.W + m.bottom.b + m.top.b, Ws + bs):
                 ok &= np.allclose(a.numpy(), r, rtol=1e-4, atol=1e-6)
         ret[rank] = bool(ok)
@@ -106,7 +132,7 @@ def _worker(rank, world, port, kind, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dot", "cat"])
+@pytest.mark.parametrize("kind", ["dot", "cat", "dot-rw", "cat-rw"])
 def test_sharded_step_equals_single_process(kind):
     world = 2
     port = _free_port()
