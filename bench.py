@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12       # B/s, MI355X spec
 F32_MFMA_PEAK = 157.3e12  # FLOP/s, v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK = 2.5e15   # FLOP/s, v_mfma_f32_32x32x16_bf16 dense peak
+# A float32 product evaluated as six bf16 MFMA terms (split of each operand into three bf16
+# pieces) can at best run at a sixth of the bf16 rate: that is the roofline of that kernel.
+BF16X3_PEAK = BF16_MFMA_PEAK / 6.0
 
 
 class KernelTimer:
@@ -77,14 +81,20 @@ def install_timers(ops, model_ref):
     def gemm_flops_bwd_weight(dz, x, dw=None, db=None, workspace=None, want_db=True):
         return 2.0 * dz.shape[0] * dz.shape[1] * x.shape[1]
 
-    def emb_fwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, **kw):
-        n_idx, D = indices.numel(), weight.shape[1]
-        return (n_idx * D * weight.element_size() + batch * num_tables * D * 4 +
+    # Algorithmic bytes of the EmbeddingBag kernels.  A call covers `num_tables` of the rank's tables
+    # (the whole ones, or its row ranges of the row-wise split ones: shard_row_begin given); of a
+    # row-wise table only the ids inside the rank's range are gathered / updated (about 1/world).
+    def emb_fwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, shard_row_begin=None, **kw):
+        D = weight.shape[1]
+        n_idx = batch * num_tables * model_ref["lookups"]
+        frac = 1.0 / model_ref["world"] if shard_row_begin is not None else 1.0
+        return (frac * n_idx * D * weight.element_size() + batch * num_tables * D * 4 +
                 n_idx * indices.element_size() + offsets.numel() * offsets.element_size())
 
-    def emb_bwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, **kw):
-        n_idx, D = indices.numel(), weight.shape[1]
-        U = model_ref["unique_rows"]
+    def emb_bwd_bytes(weight=None, indices=None, offsets=None, batch=None, num_tables=1, shard_row_begin=None, **kw):
+        D = weight.shape[1]
+        n_idx = batch * num_tables * model_ref["lookups"]
+        U = model_ref["unique_rows_rw" if shard_row_begin is not None else "unique_rows"]
         return batch * num_tables * D * 4 + 2 * U * D * weight.element_size() + n_idx * indices.element_size()
 
     def inter_fwd_bytes(x, out=None, out_ld=None):
@@ -106,9 +116,9 @@ def install_timers(ops, model_ref):
 
 
 KERNEL_OF = {
-    "linear_forward": "gemm_f32_kernel<RC,RC> (x W^T + b, ReLU)",
-    "linear_backward_data": "gemm_f32_kernel<RC,RS> (dz W, ReLU mask)",
-    "linear_backward_weight": "gemm_f32_kernel<RS,RS> split-batch + reduce_slabs + colsum (dz^T x)",
+    "linear_forward": "gemm_%s_kernel<RC,RC> (x W^T + b, ReLU)",
+    "linear_backward_data": "gemm_%s_kernel<RC,RS> (dz W, ReLU mask)",
+    "linear_backward_weight": "gemm_%s_kernel<RS,RS> split-batch + reduce_slabs + colsum (dz^T x)",
     "embbag_forward": "embbag_fwd_group_kernel",
     "embbag_backward_update": "expand_pairs + rocprim radix sort + sparse_update_kernel",
     "interact_dot_forward": "interact_dot_fwd_kernel",
@@ -158,8 +168,10 @@ def main():
         Bg = 2048
     assert Bg % world == 0
     B = Bg // world
-    model_ref = {"unique_rows": 0}
+    model_ref = {"unique_rows": 0, "unique_rows_rw": 0, "lookups": cfg.lookups, "world": world}
     timer = install_timers(ops, model_ref)
+    gemm_mode = ops.get_gemm_mode()   # 1: float32 products as six bf16 MFMA terms; 0: float32 MFMA
+    gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
     plan = None
     if args.sharding == "hybrid" and world > 1:
         from dlrm_amd.sharding import plan_hybrid
@@ -175,15 +187,20 @@ def main():
                                                   seed=1000 * (i + 1) + rank, loss=cfg.loss, dist=args.dist,
                                                   local_batch=B, shared_from=model.Tl, shared_seed=77 * (i + 1))
         # unique rows touched per batch (for the algorithmic bytes of the sparse update)
-        uniq = 0
+        uniq, uniq_rw = 0, 0
         n_per = Bg * cfg.lookups
-        for lt in range(len(local_rows)):
-            uniq += int(torch.unique(idx[lt * n_per:(lt + 1) * n_per]).numel())
-        batches.append((dense, idx, off, labels, uniq))
+        for lt, t in enumerate(model.local_table_ids):
+            u = torch.unique(idx[lt * n_per:(lt + 1) * n_per])
+            if lt < model.Tl:
+                uniq += int(u.numel())
+            else:
+                lo, hi = model.plan.row_range(t, rank)
+                uniq_rw += int(((u >= lo) & (u < hi)).sum().item())
+        batches.append((dense, idx, off, labels, (uniq, uniq_rw)))
 
     def step(i):
-        dense, idx, off, labels, uniq = batches[i % n_batches]
-        model_ref["unique_rows"] = uniq
+        dense, idx, off, labels, (uniq, uniq_rw) = batches[i % n_batches]
+        model_ref["unique_rows"], model_ref["unique_rows_rw"] = uniq, uniq_rw
         model.load_batch(dense, labels)
         return model.train_step(idx, off)
 
@@ -220,9 +237,12 @@ def main():
     for name, d in summ.items():
         sec = d["ms"] * 1e-3
         ach = d["work"] / sec if sec > 0 else 0.0
-        peak = F32_MFMA_PEAK if d["kind"] == "mfma" else HBM_PEAK
+        peak = gemm_peak if d["kind"] == "mfma" else HBM_PEAK
+        kname = KERNEL_OF.get(name, name)
+        if d["kind"] == "mfma":
+            kname = kname % gemm_name
         kernels.append({
-            "op": name, "kernel": KERNEL_OF.get(name, name), "bound": d["kind"],
+            "op": name, "kernel": kname, "bound": d["kind"],
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s" if d["kind"] == "mfma" else "TB/s",
             "frac": ach / peak, "ms_per_step": d["ms"] / args.steps, "launches_per_step": d["launches"] / args.steps,
             "avg_launch_ms": d["ms"] / max(d["launches"], 1),
@@ -236,6 +256,17 @@ def main():
                     "peak": dom["peak"] * (1e3 if dom["bound"] == "hbm" else 1.0),
                     "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
                     "avg_launch_ms": dom["avg_launch_ms"], "traffic": None}
+        if dom["bound"] == "mfma":
+            roofline["peak_note"] = ("float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6"
+                                     if gemm_mode == 1 else "float32 MFMA dense peak")
+            roofline["mfma_tflops_executed"] = dom["achieved"] * (6.0 if gemm_mode == 1 else 1.0)
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+        tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("per_op_bytes_per_launch", {})
+            for k in kernels:
+                k["traffic"] = traffic.get(k["op"])
+            roofline["traffic"] = traffic.get(dom["op"])
     emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
 
     cpu_baseline = None
@@ -253,6 +284,8 @@ def main():
                        "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
                        "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
+                       "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
+                       if gemm_mode == 1 else "float32 MFMA",
                        "parallelism": "single GPU" if world == 1 else
                        ("%s x%d + data-parallel MLP" % ("table-wise" if not model.Trw else
                                                         "table-wise + %d row-wise tables" % model.Trw, world))},
