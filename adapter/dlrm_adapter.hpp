@@ -32,6 +32,18 @@ namespace dlrm_amd {
 inline void check(int rc, const char *what) {
     if (rc != DLRM_OK) throw std::runtime_error(std::string(what) + ": " + dlrm_last_error());
 }
+// The structs of the C ABI are passed by pointer: a library built from another revision of the
+// header would read them with another layout.  Every adapter object checks this once.
+inline void check_abi() {
+    static const bool ok = [] {
+        if (dlrm_version() != DLRM_ABI_VERSION)
+            throw std::runtime_error("libdlrm_amd.so has ABI version " + std::to_string(dlrm_version()) +
+                                     ", this program was compiled against " + std::to_string(DLRM_ABI_VERSION) +
+                                     ": rebuild it");
+        return true;
+    }();
+    (void)ok;
+}
 inline void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -79,6 +91,7 @@ public:
     // and how many pages one batch can bring in on top of it (slot headroom).
     cache(int table_num, int size, int dimention, int64_t cache_pages, int64_t headroom_pages)
         : cache_size((int)cache_pages), page_count(0), T_(table_num), rows_(size), dim_(dimention) {
+        check_abi();
         vector_page_offset = 4096 / (dimention * (int)sizeof(float));   // include/data.h:211
         write_buf = new write_buffer[table_num];
         stores_.resize(table_num, nullptr);
@@ -278,7 +291,9 @@ struct emb {
 struct Net2 {
     int dense, T, D, cat;
     DeviceArray<float> W[4], b[4];
-    Net2(int dense_feature, int tables, int dim) : dense(dense_feature), T(tables), D(dim), cat(32 + tables * dim) {}
+    Net2(int dense_feature, int tables, int dim) : dense(dense_feature), T(tables), D(dim), cat(32 + tables * dim) {
+        check_abi();
+    }
     // create_fc binds global randn weights (src/dlrmtest.cpp:110-140); here the caller supplies them
     void set_layer(int i, const std::vector<float> &w, const std::vector<float> &bias) { W[i].upload(w); b[i].upload(bias); }
     static void linear(const float *x, int64_t x_ld, const float *w, int64_t w_ld, const float *bias, float *y, int64_t y_ld,

@@ -21,6 +21,9 @@ class DlrmError(RuntimeError):
     pass
 
 
+ABI_VERSION = 1001   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
+
+
 class EmbBagDesc(C.Structure):
     _fields_ = [
         ("d_weight", C.c_void_p),
@@ -94,6 +97,12 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.dlrm_last_error.restype = C.c_char_p
         _lib.dlrm_target_arch.restype = C.c_char_p
+        # the ctypes structures below mirror one revision of the header
+        if int(_lib.dlrm_version()) != ABI_VERSION:
+            v = int(_lib.dlrm_version())
+            _lib = None
+            raise DlrmError("libdlrm_amd.so has ABI version %d, this binding expects %d: rebuild the library "
+                            "(`make -C dlrm_amd/csrc`)" % (v, ABI_VERSION))
     return _lib
 
 

@@ -46,7 +46,7 @@ __global__ void copy_2d_kernel(V *__restrict__ dst, int64_t dst_ld, const V *__r
 using namespace dlrm;
 
 extern "C" const char *dlrm_last_error(void) { return err_buf(); }
-extern "C" int dlrm_version(void) { return 1000; }
+extern "C" int dlrm_version(void) { return DLRM_ABI_VERSION; }
 extern "C" const char *dlrm_target_arch(void) { return "gfx950"; }
 
 extern "C" int dlrm_table_init_uniform(void *dst, int row_dtype, int64_t n, uint64_t seed, int64_t first,

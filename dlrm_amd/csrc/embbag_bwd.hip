@@ -250,86 +250,40 @@ __device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&a
     apply_loaded<ROW, VEC16, G, NC>(p, k, acc, w, col, col_ok, lig);
 }
 
-// gradient row pointer and scale of occurrence jj (mask = 0 turns a padding slot into a no-op)
+// gradient row pointer and scale of an occurrence in bag g
 template <typename IDX>
-__device__ inline const float *occurrence(const BwdParams &p, const int32_t *__restrict__ vals, int64_t jj,
-                                          float mask, float &sc) {
+__device__ inline const float *occurrence(const BwdParams &p, uint32_t g, float &sc) {
     const IDX *off = static_cast<const IDX *>(p.off);
-    const uint32_t g = (uint32_t)vals[jj];
     const uint32_t t = g / (uint32_t)p.B;
     const uint32_t b = g - t * (uint32_t)p.B;
-    sc = mask;
+    sc = 1.0f;
     if (p.mean) {
         const int64_t s0 = (int64_t)off[g];
         const int64_t e0 = ((int64_t)g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
-        sc = mask / (float)(e0 - s0);
+        sc = 1.0f / (float)(e0 - s0);
     }
     return p.grad + (int64_t)b * p.grad_ld + (int64_t)t * p.D;
 }
 
-// Sum of the gradient rows of the occurrences of row k in sorted positions [i, seg_end) and either
-// the optimizer step (the piece is a whole run) or a store to `partial` (pieces of longer runs:
-// 2 slots per kSegLen positions, [0] the piece that starts on the boundary, [1] the piece that
-// ends on it; combine_runs_kernel adds them up).
-template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
-__device__ inline void sum_segment(const BwdParams &p, const KEY *__restrict__ keys, const int32_t *__restrict__ vals,
-                                   float *__restrict__ partial, int dpad, int64_t i, KEY k, bool run_start,
-                                   const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
-    constexpr int NF = RowRW<ROW, VEC16>::NF;
-    int64_t seg_end = (i / kSegLen + 1) * kSegLen;
-    if (seg_end > p.n_idx) seg_end = p.n_idx;
-    float acc[NC][NF];
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-#pragma unroll
-        for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
-    // occurrences kRunUnroll at a time: their gradient rows are fetched together (slots past the
-    // end of the run re-read occurrence j with weight 0, so the loads need no branches and stay
-    // in flight together); the sum keeps position order
-    constexpr int kRunUnroll = 8;
-    int64_t j = i;
-    do {
-        const float *gp[kRunUnroll];
-        float sc[kRunUnroll];
-#pragma unroll
-        for (int u = 0; u < kRunUnroll; u++) {
-            const int64_t jj = j + u;
-            const bool ok = jj < seg_end && keys[jj < p.n_idx ? jj : p.n_idx - 1] == k;
-            gp[u] = occurrence<IDX>(p, vals, ok ? jj : j, ok ? 1.0f : 0.0f, sc[u]);
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (col_ok[c]) {
-                float v[kRunUnroll][NF];
-#pragma unroll
-                for (int u = 0; u < kRunUnroll; u++) load_grad<NF>(gp[u] + col[c], v[u]);
-#pragma unroll
-                for (int u = 0; u < kRunUnroll; u++)
-#pragma unroll
-                    for (int q = 0; q < NF; q++) acc[c][q] += v[u][q] * sc[u];
-            }
-        j += kRunUnroll;
-    } while (j < seg_end && keys[j] == k);
-    const bool continues = seg_end < p.n_idx && keys[seg_end - 1] == k && keys[seg_end] == k;
-    if (run_start && !continues) {
-        apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
-    } else {
-        float *dst = partial + (2 * (i / kSegLen) + ((i % kSegLen) == 0 ? 0 : 1)) * (int64_t)dpad;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (col_ok[c]) store_vec<NF>(dst + col[c], acc[c]);
-    }
-}
-
-// Each G-lane group owns kPosPerGroup consecutive sorted positions.
-//  * Rows that occur once in the batch (the common case on large tables): their gradient rows and
-//    the table rows of all of the group's positions are fetched together, updated and stored --
-//    kPosPerGroup independent row read-modify-writes in flight per group.
-//  * A position that starts a longer run (or sits on a kSegLen boundary inside one) sums its piece
-//    of the run (sum_segment).
-// DLRM_DUP_LAST_WINS: only the last occurrence of a row counts, which makes every row a
-// single-occurrence update of that position.
-constexpr int kPosPerGroup = 4;
+// Segmented reduction by row over the sorted occurrences, fused with the optimizer step.
+//
+// A workgroup owns BLOCK_POS consecutive sorted positions (one or two stretches of kSegLen), each
+// G-lane group PPG consecutive positions of it, walked kChunk at a time: the chunk's gradient rows --
+// and the table rows of the runs that end in it -- are fetched together (up to 2*kChunk independent
+// 16-byte loads per lane), then added up in position order.
+//  * A run that lies inside one group is summed and applied there: every touched row is read once
+//    and written once.  On large tables almost every run is a single position.
+//  * Pieces of runs that cross group boundaries meet in LDS: per group a "head" piece (the run came in
+//    from the previous group; flag 1 = it ends inside this group, 2 = it runs through the whole group)
+//    and a "tail" piece (a run that starts in this group and leaves it).  The group in which a run
+//    ends adds its pieces in position order and applies the update.
+//  * Pieces of runs that cross a kSegLen boundary go to `partial` (2 slots per stretch: [0] the piece
+//    that starts on the boundary, [1] the piece that starts inside and runs to the end);
+//    combine_runs_kernel adds them up.  A table of 3 rows hit by a 65536-sample batch is 20000-long
+//    runs: every group of every workgroup sums its share.
+// DLRM_DUP_LAST_WINS: only the last occurrence of a row counts, so every position is its own run and
+// only run ends are applied.
+constexpr int kChunk = 4;
 
 template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
 __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
@@ -338,34 +292,31 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
     constexpr int GROUPS = kBwdThreads / G;
-    constexpr int P = kPosPerGroup;
-    const int grp = threadIdx.x / G, lig = threadIdx.x % G;
-    const int64_t i0 = ((int64_t)blockIdx.x * GROUPS + grp) * P;
-    if (i0 >= p.n_idx) return;
+    constexpr int PPG = (kSegLen / GROUPS) > kChunk ? (kSegLen / GROUPS) : kChunk;   // positions per group
+    constexpr int GPS = kSegLen / PPG;                                                // groups per stretch
+    constexpr int BLOCK_POS = GROUPS * PPG;
+    constexpr int DP = NC * G * NF;                                                   // floats per piece
+    static_assert(GROUPS % GPS == 0 && PPG % kChunk == 0 && BLOCK_POS % kSegLen == 0, "tiling");
+    static_assert(GROUPS * 2 * DP * 4 <= 48 * 1024, "pieces must fit LDS");
 
-    // keys of positions i0-1 .. i0+P; positions outside [0, n) read as "no row"
+    __shared__ KEY s_key[BLOCK_POS + 2];         // keys of positions b0-1 .. b0+BLOCK_POS
+    __shared__ int32_t s_val[BLOCK_POS];
+    __shared__ int s_head[GROUPS], s_tail[GROUPS];
+    __shared__ __attribute__((aligned(16))) float s_piece[GROUPS][2][DP];
+
+    const int tid = threadIdx.x, grp = tid / G, lig = tid % G;
+    const int64_t b0 = (int64_t)blockIdx.x * BLOCK_POS;
     const KEY none = ~(KEY)0;
-    KEY kw[P + 2];
-#pragma unroll
-    for (int u = 0; u < P + 2; u++) {
-        const int64_t idx = i0 - 1 + u;
-        kw[u] = (idx >= 0 && idx < p.n_idx) ? keys[idx] : none;
+    for (int i = tid; i < BLOCK_POS + 2; i += kBwdThreads) {
+        const int64_t q = b0 - 1 + i;
+        s_key[i] = (q >= 0 && q < p.n_idx) ? keys[q] : none;
     }
-    bool fast[P], slow[P], any_fast = false;
-#pragma unroll
-    for (int u = 0; u < P; u++) {
-        const KEY k = kw[u + 1];
-        const bool valid = (int64_t)k < p.total_rows && k != none;   // bad indices carry key == total_rows
-        const bool run_start = kw[u] != k, next_same = kw[u + 2] == k;
-        if (p.last_wins) {
-            fast[u] = valid && !next_same;
-            slow[u] = false;
-        } else {
-            fast[u] = valid && run_start && !next_same;
-            slow[u] = valid && !fast[u] && (run_start || ((i0 + u) % kSegLen) == 0);
-        }
-        any_fast |= fast[u];
-    }
+    for (int i = tid; i < BLOCK_POS; i += kBwdThreads) s_val[i] = b0 + i < p.n_idx ? vals[b0 + i] : 0;
+    if (tid < GROUPS) { s_head[tid] = 0; s_tail[tid] = 0; }
+    __syncthreads();
+
+    auto K = [&](int pos) { return s_key[pos + 1]; };                       // key of block-local position
+    auto valid = [&](KEY k) { return (int64_t)k < p.total_rows && k != none; };   // bad indices carry total_rows
 
     int col[NC];
     bool col_ok[NC];
@@ -374,46 +325,148 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
         col[c] = (c * G + lig) * NF;
         col_ok[c] = col[c] < p.D;
     }
-
-    if (any_fast) {
-        // slots that are not single-occurrence rows re-read the group's first fast slot
-        int first = 0;
+    auto zero = [&](float (&a)[NC][NF]) {
 #pragma unroll
-        for (int u = P - 1; u >= 0; u--)
-            if (fast[u]) first = u;
-        const float *gp[P];
-        float sc[P];
-        int64_t row[P];
+        for (int c = 0; c < NC; c++)
 #pragma unroll
-        for (int u = 0; u < P; u++) {
-            const int uu = fast[u] ? u : first;
-            row[u] = (int64_t)kw[uu + 1];
-            gp[u] = occurrence<IDX>(p, vals, i0 + uu, 1.0f, sc[u]);
+            for (int q = 0; q < NF; q++) a[c][q] = 0.f;
+    };
+    auto put_piece = [&](int g, int slot, const float (&a)[NC][NF]) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) store_vec<NF>(&s_piece[g][slot][(c * G + lig) * NF], a[c]);
+    };
+    auto add_piece = [&](int g, int slot, float (&a)[NC][NF]) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float v[NF];
+            load_vec<NF>(&s_piece[g][slot][(c * G + lig) * NF], v);
+#pragma unroll
+            for (int q = 0; q < NF; q++) a[c][q] += v[q];
         }
-        float g[P][NC][NF], w[P][NC][NF];
+    };
+
+    const int gp0 = grp * PPG;
+    const bool accumulate = !p.last_wins;
+    // the run at the group's first position came in from the previous group
+    bool ext = accumulate && valid(K(gp0)) && K(gp0 - 1) == K(gp0);
+    float acc[NC][NF];
+    zero(acc);
+
+    for (int c0 = 0; c0 < PPG; c0 += kChunk) {
+        const int q0 = gp0 + c0;
+        bool v[kChunk], endr[kChunk], need_w[kChunk];
+        bool any = false, any_w = false, e = ext;
+        int fu = 0, fw = -1;
 #pragma unroll
-        for (int u = 0; u < P; u++)
+        for (int u = kChunk - 1; u >= 0; u--) {
+            v[u] = valid(K(q0 + u));
+            endr[u] = K(q0 + u + 1) != K(q0 + u);
+            if (v[u]) fu = u;
+            any |= v[u];
+        }
+        if (!any) continue;
 #pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (col_ok[c]) {
-                    load_grad<NF>(gp[u] + col[c], g[u][c]);
-                    RW::load(p.w, row[u] * p.D + col[c], w[u][c]);
-                }
+        for (int u = 0; u < kChunk; u++) {
+            need_w[u] = v[u] && endr[u] && !e;      // a run ends here and this group holds all of it
+            if (v[u] && endr[u]) e = false;
+            if (need_w[u] && fw < 0) fw = u;
+            any_w |= need_w[u];
+        }
+        // slots without work re-read the first slot that has some: the loads need no branches
+        const float *gp[kChunk];
+        float sc[kChunk];
 #pragma unroll
-        for (int u = 0; u < P; u++)
-            if (fast[u]) {
+        for (int u = 0; u < kChunk; u++) gp[u] = occurrence<IDX>(p, (uint32_t)s_val[q0 + (v[u] ? u : fu)], sc[u]);
+        float g[kChunk][NC][NF], w[kChunk][NC][NF];
+        if (any_w) {
+            int64_t row[kChunk];
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) row[u] = (int64_t)K(q0 + (need_w[u] ? u : fw));
+#pragma unroll
+            for (int u = 0; u < kChunk; u++)
 #pragma unroll
                 for (int c = 0; c < NC; c++)
+                    if (col_ok[c]) {
+                        load_grad<NF>(gp[u] + col[c], g[u][c]);
+                        RW::load(p.w, row[u] * p.D + col[c], w[u][c]);
+                    }
+        } else {
 #pragma unroll
-                    for (int q = 0; q < NF; q++) g[u][c][q] *= sc[u];
-                apply_loaded<ROW, VEC16, G, NC>(p, row[u], g[u], w[u], col, col_ok, lig);
+            for (int u = 0; u < kChunk; u++)
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    if (col_ok[c]) load_grad<NF>(gp[u] + col[c], g[u][c]);
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) {
+            if (!v[u]) continue;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < NF; q++) acc[c][q] = accumulate ? acc[c][q] + g[u][c][q] * sc[u] : g[u][c][q] * sc[u];
+            if (!endr[u]) continue;
+            if (ext) {                       // the run started in an earlier group: hand the piece over
+                put_piece(grp, 0, acc);
+                if (lig == 0) s_head[grp] = 1;
+                ext = false;
+            } else {
+                apply_loaded<ROW, VEC16, G, NC>(p, (int64_t)K(q0 + u), acc, w[u], col, col_ok, lig);
             }
+            zero(acc);
+        }
     }
+    if (accumulate && valid(K(gp0 + PPG - 1)) && K(gp0 + PPG) == K(gp0 + PPG - 1)) {   // the last run leaves the group
+        put_piece(grp, ext ? 0 : 1, acc);
+        if (lig == 0) {
+            if (ext) s_head[grp] = 2;
+            else s_tail[grp] = 1;
+        }
+    }
+    if (!accumulate) return;
+    __syncthreads();
+
+    const int seg = grp / GPS, seg_first = seg * GPS;
+    const int64_t seg_global = b0 / kSegLen + seg;
+    // sum of the pieces of the run that reaches into group `last` (whose piece there is in the head
+    // slot); returns the group in which the run started, or seg_first - 1 if it came in from before
+    // this stretch
+    auto gather = [&](int last, float (&a)[NC][NF]) {
+        int j = last - 1;
+        while (j >= seg_first && s_head[j] == 2) j--;
+        zero(a);
+        if (j >= seg_first) add_piece(j, 1, a);
+        for (int q = j + 1; q <= last; q++) add_piece(q, 0, a);
+        return j;
+    };
+    if (s_head[grp] == 1) {                  // a run that came in from earlier groups ends here
+        const KEY k = K(gp0);
+        float a[NC][NF];
+        const bool from_inside = gather(grp, a) >= seg_first;
+        if (from_inside || K(seg_first * PPG - 1) != k) {
+            apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, a, col, col_ok, lig);
+        } else {                             // it started before this stretch
+            float *dst = partial + (2 * seg_global + 0) * (int64_t)dpad;
 #pragma unroll
-    for (int u = 0; u < P; u++)
-        if (slow[u])
-            sum_segment<IDX, KEY, ROW, VEC16, G, NC>(p, keys, vals, partial, dpad, i0 + u, kw[u + 1], kw[u] != kw[u + 1],
-                                                     col, col_ok, lig);
+            for (int c = 0; c < NC; c++)
+                if (col_ok[c]) store_vec<NF>(dst + col[c], a[c]);
+        }
+    }
+    if (grp == seg_first + GPS - 1 && (s_head[grp] == 2 || s_tail[grp] == 1)) {   // a run leaves the stretch
+        float a[NC][NF];
+        bool on_boundary = false;            // does the piece start at the first position of the stretch?
+        if (s_tail[grp] == 1) {
+            zero(a);
+            add_piece(grp, 1, a);
+        } else {
+            const int j = gather(grp, a);
+            // from before the stretch, or the first group is one single run that leaves it
+            on_boundary = j < seg_first || (j == seg_first && K(seg_first * PPG) == K(seg_first * PPG + PPG - 1));
+        }
+        float *dst = partial + (2 * seg_global + (on_boundary ? 0 : 1)) * (int64_t)dpad;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (col_ok[c]) store_vec<NF>(dst + col[c], a[c]);
+    }
 }
 
 // One group per kSegLen positions: if a run starts inside this stretch and goes on beyond it, sum
@@ -480,7 +533,9 @@ __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, 
 template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
 static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *vals, float *partial, int dpad,
                          hipStream_t s) {
-    const int64_t blocks = ceil_div(p.n_idx, (int64_t)(kBwdThreads / G) * kPosPerGroup);
+    constexpr int kGroups = kBwdThreads / G;
+    constexpr int kPpg = (kSegLen / kGroups) > kChunk ? (kSegLen / kGroups) : kChunk;
+    const int64_t blocks = ceil_div(p.n_idx, (int64_t)kGroups * kPpg);
     hipLaunchKernelGGL((sparse_update_kernel<IDX, KEY, ROW, VEC16, G, NC>), dim3((unsigned)blocks),
                        dim3(kBwdThreads), 0, s, p, keys, vals, partial, dpad);
     DLRM_LAUNCH_CHECK();
@@ -507,7 +562,8 @@ static int dispatch_update(const BwdParams &p, const KEY *keys, const int32_t *v
     if (lanes <= 32) return launch_update<IDX, KEY, ROW, 1, 32, 1>(p, keys, vals, partial, dpad, s);
     if (lanes <= 64) return launch_update<IDX, KEY, ROW, 1, 64, 1>(p, keys, vals, partial, dpad, s);
     if (lanes <= 128) return launch_update<IDX, KEY, ROW, 1, 64, 2>(p, keys, vals, partial, dpad, s);
-    return launch_update<IDX, KEY, ROW, 1, 64, 4>(p, keys, vals, partial, dpad, s);
+    if constexpr (sizeof(ROW) == 4) return launch_update<IDX, KEY, ROW, 1, 64, 4>(p, keys, vals, partial, dpad, s);
+    return set_error(DLRM_ERR_INVALID, "dim=%d is too wide for the sparse update (max 1024)", p.D);
 }
 
 template <typename IDX, typename KEY>
@@ -587,7 +643,7 @@ extern "C" int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_
     const bool vec16 = (e->dim % nf == 0) && (reinterpret_cast<uintptr_t>(e->d_weight) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(d_grad) % 16 == 0) && (grad_ld % 4 == 0) && (e->dim % 4 == 0);
     const int lanes = vec16 ? e->dim / nf : e->dim;
-    DLRM_REQUIRE(lanes <= 256, "dim=%d is too wide for this kernel", e->dim);
+    DLRM_REQUIRE(lanes <= 256 && e->dim <= 1024, "dim=%d is too wide for this kernel (max 1024)", e->dim);
 
     hipStream_t s = as_stream(stream);
     const bool k64 = key_bits(e->total_rows) > 32;

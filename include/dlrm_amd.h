@@ -47,7 +47,11 @@ enum { DLRM_ACT_NONE = 0, DLRM_ACT_RELU = 1 };
 
 /* Message of the last failing call on this thread ("" if none). */
 const char *dlrm_last_error(void);
-/* ABI version of the library: major*1000 + minor. */
+/* ABI version: major*1000 + minor.  It changes whenever a struct of this header changes layout.
+ * dlrm_version() is what the loaded library was built with; a caller compiled against another
+ * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
+ * before their first call). */
+#define DLRM_ABI_VERSION 1001
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);

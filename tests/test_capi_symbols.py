@@ -1,3 +1,4 @@
+import os
 """CPU-side checks of the drop-in boundary: the shared library loads and
 exports every symbol the header declares; bad arguments are rejected with a
 message instead of reaching a kernel."""
@@ -29,3 +30,11 @@ def test_invalid_descriptor_is_rejected_without_launch():
     with pytest.raises(_capi.DlrmError):
         _capi.check(rc)
     assert L.dlrm_embbag_forward(None, None, C.c_int64(0), None) == 1
+
+
+def test_binding_and_header_agree_on_abi_version():
+    import re
+    from dlrm_amd import _capi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dlrm_amd.h")).read()
+    m = re.search(r"#define\s+DLRM_ABI_VERSION\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == _capi.ABI_VERSION

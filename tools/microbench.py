@@ -120,6 +120,40 @@ def sparse(rows=10_000_000, B=65536):
     return out
 
 
+def sparse_mlperf(B=65536, D=128):
+    """Fused sparse update on subsets of the MLPerf tables (one id per bag): where does the time go?"""
+    from dlrm_amd.model import MLPERF_TABLE_ROWS as R
+    groups = {"huge(>=20M)": [r for r in R if r >= 20_000_000], "mid(10k..20M)": [r for r in R if 10_000 <= r < 20_000_000],
+              "small(200..10k)": [r for r in R if 200 <= r < 10_000], "tiny(<200)": [r for r in R if r < 200],
+              "all": list(R)}
+    out = []
+    for name, rows in groups.items():
+        T = len(rows)
+        tro = torch.tensor([0] + list(torch.tensor(rows).cumsum(0)), dtype=torch.int64, device="cuda")
+        w = torch.empty(int(tro[-1]), D, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(3)
+        idx = torch.cat([torch.randint(0, r, (B,), generator=g, device="cuda", dtype=torch.int32) for r in rows])
+        off = torch.arange(T * B + 1, device="cuda", dtype=torch.int32)
+        grad = torch.randn(B, T * D, device="cuda")
+        o = torch.empty(B, T * D, device="cuda")
+        ws = [None]
+
+        def run():
+            ws[0] = ops.embbag_backward_update(w, idx, off, B, grad, T, tro, _capi.POOL_SUM, True, lr=0.0,
+                                               workspace=ws[0])
+        t_b = timeit(run, iters=5, warmup=1)
+        t_f = timeit(lambda: ops.embbag_forward(w, idx, off, B, T, tro, _capi.POOL_SUM, True, out=o, out_ld=T * D),
+                     iters=5, warmup=1)
+        U = sum(int(torch.unique(idx[t * B:(t + 1) * B]).numel()) for t in range(T))
+        rec = {"tables": name, "T": T, "unique": U, "bwd_us": t_b * 1e6, "fwd_us": t_f * 1e6,
+               "bwd_GBps": (B * T * D * 4 + 2 * U * D * 4 + B * T * 4) / t_b / 1e9,
+               "bwd_ns_per_position": t_b * 1e9 / (B * T)}
+        out.append(rec)
+        print(json.dumps(rec))
+        del w
+    return out
+
+
 def interact(B=65536, F=27, D=128):
     x = torch.randn(B, F, D, device="cuda")
     n_out = D + F * (F - 1) // 2
@@ -139,7 +173,7 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     if os.environ.get("GEMM_MODE"):
         ops.set_gemm_mode(int(os.environ["GEMM_MODE"]))
-    res = {"gemm": gemm, "gemm1024": lambda: gemm([(1024, 1024)]), "embbag": embbag, "sparse": sparse,
+    res = {"gemm": gemm, "gemm1024": lambda: gemm([(1024, 1024)]), "embbag": embbag, "sparse": sparse, "sparse_mlperf": sparse_mlperf,
            "interact": interact}[which]()
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"), indent=1)
