@@ -28,19 +28,34 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const float *__restr
     __shared__ float s[kLossThreads / 64];
     const float inv_n = 1.0f / (float)mean_over;
     float a = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += kLossThreads) {
-        const float x = pred[i], t = target[i];
-        float g;
-        if constexpr (BCE) {
-            a += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            g = (1.0f / (1.0f + expf(-x)) - t) * inv_n;
-        } else {
-            const float d = x - t;
-            a += d * d;
-            g = 2.0f * d * inv_n;
-            if (relu_mask && !(x > 0.f)) g = 0.f;
+    // kU elements per thread at a time: their loads are independent and in flight together (a plain
+    // strided loop pays one memory round trip per element and per thread)
+    constexpr int kU = 8;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)kLossThreads * kU) {
+        float x[kU], t[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int64_t i = i0 + (int64_t)u * kLossThreads;
+            const int64_t ic = i < n ? i : n - 1;
+            x[u] = pred[ic];
+            t[u] = target[ic];
         }
-        if (dpred) dpred[i] = g;
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int64_t i = i0 + (int64_t)u * kLossThreads;
+            if (i >= n) break;
+            float g;
+            if constexpr (BCE) {
+                a += fmaxf(x[u], 0.f) - x[u] * t[u] + log1pf(expf(-fabsf(x[u])));
+                g = (1.0f / (1.0f + expf(-x[u])) - t[u]) * inv_n;
+            } else {
+                const float d = x[u] - t[u];
+                a += d * d;
+                g = 2.0f * d * inv_n;
+                if (relu_mask && !(x[u] > 0.f)) g = 0.f;
+            }
+            if (dpred) dpred[i] = g;
+        }
     }
     const float tot = block_sum(a, s);
     if (threadIdx.x == 0 && loss) *loss = tot * inv_n;

@@ -172,8 +172,11 @@ class MLPStack:
 
 class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
-                 seed=0, process_group=None, init_tables=True):
-        """batch: LOCAL batch size (samples whose MLP runs on this rank)."""
+                 seed=0, process_group=None, init_tables=True, overlap=None):
+        """batch: LOCAL batch size (samples whose MLP runs on this rank).
+        overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
+        MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
+        concurrent HBM traffic buys nothing: measured 0.2 %)."""
         _capi.lib()  # fail loudly if the HIP library is missing
         self.cfg, self.B, self.rank, self.world, self.pg = cfg, batch, rank, world, process_group
         self.Bg = batch * world
@@ -258,6 +261,12 @@ class DLRM:
         self.loss = torch.zeros(1, **f32)
         self.ws_dense = None
         self.ws_sparse = None
+        # The EmbeddingBag kernels (and, sharded, their exchanges) are HBM / link bound, the bottom MLP
+        # is matrix-pipe bound and the two touch different columns of `feat` / `dfeat`: they can run
+        # concurrently, the embedding side on a second HIP stream.
+        if overlap is None:
+            overlap = world > 1
+        self.side = torch.cuda.Stream(device=dev) if (overlap and self.dev.type == "cuda") else None
 
         # ---- exchange buffers (sharded only)
         if world > 1:
@@ -373,8 +382,16 @@ class DLRM:
     def forward(self, indices, offsets):
         """Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
         cfg = self.cfg
-        self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
-        self.embedding_forward(indices, offsets)
+        if self.side is None:
+            self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
+            self.embedding_forward(indices, offsets)
+        else:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)          # earlier readers of feat and the input copies are done
+            with torch.cuda.stream(self.side):
+                self.embedding_forward(indices, offsets)
+            self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
+            main.wait_stream(self.side)
         if cfg.interaction == "dot":
             ops.interact_dot_forward(self.feat.view(self.B, cfg.num_features, cfg.dim), out=self.inter,
                                      out_ld=self.inter_ld)
@@ -408,10 +425,18 @@ class DLRM:
             # bottom part of the concatenation is a ReLU output, the pooled part is not
             ops.linear_backward_data(dz0, self.top.W[0][:, :nb], relu_mask=self.feat[:, :nb], out=self.dfeat[:, :nb])
             ops.linear_backward_data(dz0, self.top.W[0][:, nb:], out=self.dfeat[:, nb:cfg.top_in])
-        # sparse rows (exchange + fused update), then bottom MLP
-        self.embedding_backward_update(indices, offsets)
+        # sparse rows (exchange + fused update) beside the bottom MLP's backward
+        if self.side is None:
+            self.embedding_backward_update(indices, offsets)
+        else:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)          # dfeat is complete
+            with torch.cuda.stream(self.side):
+                self.embedding_backward_update(indices, offsets)
         self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
                                              self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)   # rows are updated before anyone reuses dfeat
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grads, group=self.pg)

@@ -37,11 +37,13 @@ def get_state(m):
 
 @pytest.mark.parametrize("name", ["mlperf_like", "kaggle_like", "rmc1_like", "adagrad_bf16rows_off"])
 @pytest.mark.parametrize("ragged", [False, True])
-def test_train_step_matches_oracle(oracle, name, ragged):
+@pytest.mark.parametrize("overlap", [False, True])      # True: embedding side on a second HIP stream
+def test_train_step_matches_oracle(oracle, name, ragged, overlap):
     from dlrm_amd.model import DLRM
     cfg = small_cfgs()[name]
     B = 37
-    m = DLRM(cfg, B, seed=3)
+    m = DLRM(cfg, B, seed=3, overlap=overlap)
+    assert (m.side is not None) == overlap
     if name == "rmc1_like":
         # positive biases keep the all-ReLU reference model alive
         for b in m.bottom.b + m.top.b:
