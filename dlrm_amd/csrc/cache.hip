@@ -107,30 +107,66 @@ __device__ inline int table_of_pos(const IdLayout &l, int T, int64_t i) {
 
 // ---- lookup ----------------------------------------------------------------
 
+// Wave-level aggregation of counter updates: lanes of a wave almost always work on the same table
+// (ids and sorted pages are grouped by table), so one lane adds the wave's total instead of 64 lanes
+// queueing on one address.  `valid` lanes carry table `t` and a 0/1 flag per counter.
+__device__ inline void wave_add2(int64_t *counters, bool valid, int t, int ca, bool fa, int cb, bool fb) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int t0 = __shfl(t, leader, 64);
+        const bool mine = valid && t == t0;
+        const unsigned long long same = __ballot(mine);
+        const int na = __popcll(__ballot(mine && fa)), nb = __popcll(__ballot(mine && fb));
+        if (lane == leader) {
+            if (na) atomicAdd((unsigned long long *)&counters[t0 * kNumCounters + ca], (unsigned long long)na);
+            if (nb) atomicAdd((unsigned long long *)&counters[t0 * kNumCounters + cb], (unsigned long long)nb);
+        }
+        todo &= ~same;
+    }
+}
+
+// position for every lane with `take` in a list whose length lives at *count (one atomic per wave)
+__device__ inline int64_t wave_append(int64_t *count, bool take) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long w = __ballot(take);
+    if (w == 0) return -1;
+    const int leader = __ffsll((long long)w) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long *)count, (unsigned long long)__popcll(w));
+    base = __shfl(base, leader, 64);
+    return take ? (int64_t)base + __popcll(w & ((1ull << lane) - 1ull)) : -1;
+}
+
 // cache::read() miss detection (src/emb_cache.cpp:410-438) + lru_page() touch (:317-352)
 template <typename IDX>
 __global__ __launch_bounds__(kCacheThreads) void probe_kernel(TableGeom g, CacheDev d, IdLayout l, const IDX *ids,
                                                                int64_t n) {
     const uint32_t epoch = (uint32_t)d.scalars[S_EPOCH];
-    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCacheThreads) {
-        const int t = table_of_pos(l, g.T, i);
-        const int64_t id = (int64_t)ids[i];
-        if (id < 0 || id >= g.rows[t]) {
-            atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_BAD_ID);
-            continue;
-        }
-        const int64_t gp = g.page_base[t] + id / g.vpo;
-        const int32_t s = d.page_map[gp];
-        if (s >= 0) {
-            atomicExch(&d.slot_epoch[s], epoch);
-            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_HIT], 1ull);
-        } else {
-            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_MISS], 1ull);
-            if (s == -1 && atomicCAS(&d.page_map[gp], -1, -2) == -1) {
-                const int64_t pos = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_N_MISS], 1ull);
-                d.miss[pos] = (int32_t)gp;
+    // every lane of a wave makes the same number of trips (the ballots below need the whole wave)
+    for (int64_t base = (int64_t)blockIdx.x * kCacheThreads; base < n; base += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = base + threadIdx.x;
+        bool valid = i < n, hit = false, claim = false;
+        int t = 0;
+        int64_t gp = 0;
+        if (valid) {
+            t = table_of_pos(l, g.T, i);
+            const int64_t id = (int64_t)ids[i];
+            if (id < 0 || id >= g.rows[t]) {
+                atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_BAD_ID);
+                valid = false;
+            } else {
+                gp = g.page_base[t] + id / g.vpo;
+                const int32_t s = d.page_map[gp];
+                hit = s >= 0;
+                if (hit) d.slot_epoch[s] = epoch;   // every writer of this call stores the same value
+                else claim = s == -1 && atomicCAS(&d.page_map[gp], -1, -2) == -1;   // first to see the page missing
             }
         }
+        wave_add2(d.counters, valid, t, C_HIT, hit, C_MISS, !hit);
+        const int64_t pos = wave_append(&d.scalars[S_N_MISS], claim);
+        if (claim) d.miss[pos] = (int32_t)gp;
     }
 }
 
@@ -139,21 +175,26 @@ __global__ __launch_bounds__(kCacheThreads) void assign_kernel(TableGeom g, Cach
     const int64_t n_miss = d.scalars[S_N_MISS];
     const int64_t head = d.scalars[S_HEAD], avail = d.scalars[S_TAIL] - head;
     const uint32_t epoch = (uint32_t)d.scalars[S_EPOCH];
-    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n_miss;
-         i += (int64_t)gridDim.x * kCacheThreads) {
-        const int64_t gp = d.miss_sorted[i];
-        const int t = table_of_page(g, gp);
-        if (i < avail) {
-            const int32_t s = d.ring[(head + i) % d.S];
-            d.page_map[gp] = s;
-            d.slot_gp[s] = (int32_t)gp;
-            d.slot_epoch[s] = epoch;
-            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_READ], 1ull);
-            atomicAdd((unsigned long long *)&d.counters[t * kNumCounters + C_RESIDENT], 1ull);
-        } else {
-            d.page_map[gp] = -1;
-            atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_POOL_EXHAUSTED);
+    for (int64_t base = (int64_t)blockIdx.x * kCacheThreads; base < n_miss; base += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n_miss;
+        bool placed = false;
+        int t = 0;
+        if (valid) {
+            const int64_t gp = d.miss_sorted[i];
+            t = table_of_page(g, gp);
+            if (i < avail) {
+                const int32_t s = d.ring[(head + i) % d.S];
+                d.page_map[gp] = s;
+                d.slot_gp[s] = (int32_t)gp;
+                d.slot_epoch[s] = epoch;
+                placed = true;
+            } else {
+                d.page_map[gp] = -1;
+                atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_POOL_EXHAUSTED);
+            }
         }
+        wave_add2(d.counters, valid, t, C_READ, placed, C_RESIDENT, placed);
     }
 }
 
@@ -242,6 +283,12 @@ __global__ void plan_reclaim_kernel(TableGeom g, CacheDev d) {
 
 __global__ __launch_bounds__(kCacheThreads) void age_hist_kernel(TableGeom g, CacheDev d) {
     if (d.scalars[S_PASSES] == 0) return;
+    // ages cluster in a few bins per table: count in LDS first, one global atomic per non-empty bin
+    // and workgroup (tables beyond the LDS window go straight to global memory)
+    constexpr int kLdsTables = 8;
+    __shared__ unsigned int h[kLdsTables * kAgeBins];
+    for (int i = threadIdx.x; i < kLdsTables * kAgeBins; i += kCacheThreads) h[i] = 0;
+    __syncthreads();
     const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
     for (int64_t s = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; s < d.S; s += (int64_t)gridDim.x * kCacheThreads) {
         const int32_t gp = d.slot_gp[s];
@@ -249,8 +296,13 @@ __global__ __launch_bounds__(kCacheThreads) void age_hist_kernel(TableGeom g, Ca
         const int t = table_of_page(g, gp);
         uint32_t age = now - d.slot_epoch[s];
         if (age > kAgeBins - 1) age = kAgeBins - 1;
-        atomicAdd(&d.hist[t * kAgeBins + age], 1u);
+        if (t < kLdsTables) atomicAdd(&h[t * kAgeBins + age], 1u);
+        else atomicAdd(&d.hist[t * kAgeBins + age], 1u);
     }
+    __syncthreads();
+    const int nt = g.T < kLdsTables ? g.T : kLdsTables;
+    for (int i = threadIdx.x; i < nt * kAgeBins; i += kCacheThreads)
+        if (h[i]) atomicAdd(&d.hist[i], h[i]);
 }
 
 // per table: the youngest age a* such that the pages of age >= a* number at least k_t
@@ -274,14 +326,22 @@ __global__ void threshold_kernel(TableGeom g, CacheDev d) {
 __global__ __launch_bounds__(kCacheThreads) void collect_candidates_kernel(TableGeom g, CacheDev d) {
     if (d.scalars[S_PASSES] == 0) return;
     const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
-    for (int64_t s = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; s < d.S; s += (int64_t)gridDim.x * kCacheThreads) {
-        const int32_t gp = d.slot_gp[s];
-        if (gp < 0) continue;
-        const int t = table_of_page(g, gp);
-        uint32_t age = now - d.slot_epoch[s];
-        if (age > kAgeBins - 1) age = kAgeBins - 1;
-        if ((int)age >= d.thr_age[t]) {
-            const int64_t pos = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_N_CAND], 1ull);
+    for (int64_t base = (int64_t)blockIdx.x * kCacheThreads; base < d.S; base += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t s = base + threadIdx.x;
+        bool take = false;
+        int t = 0;
+        int32_t gp = -1;
+        if (s < d.S) {
+            gp = d.slot_gp[s];
+            if (gp >= 0) {
+                t = table_of_page(g, gp);
+                uint32_t age = now - d.slot_epoch[s];
+                if (age > kAgeBins - 1) age = kAgeBins - 1;
+                take = (int)age >= d.thr_age[t];
+            }
+        }
+        const int64_t pos = wave_append(&d.scalars[S_N_CAND], take);
+        if (take) {
             d.cand_key[pos] = ((uint64_t)t << 58) | ((uint64_t)(d.slot_epoch[s] & 0x3ffffffu) << 32) | (uint32_t)gp;
             d.cand_val[pos] = (int32_t)s;
         }
