@@ -129,10 +129,11 @@ struct RowRW;
 template <>
 struct RowRW<float, 1> {
     static constexpr int NF = 4;
-    __device__ static void load(const void *w, int64_t e, float (&v)[4]) {
-        const float4 x = *reinterpret_cast<const float4 *>(static_cast<const float *>(w) + e);
-        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    typedef float4 Raw;
+    __device__ static Raw load_raw(const void *w, int64_t e) {
+        return *reinterpret_cast<const float4 *>(static_cast<const float *>(w) + e);
     }
+    __device__ static void unpack(const Raw &x, float (&v)[4]) { v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
     __device__ static void store(void *w, int64_t e, const float (&v)[4]) {
         *reinterpret_cast<float4 *>(static_cast<float *>(w) + e) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -140,8 +141,11 @@ struct RowRW<float, 1> {
 template <>
 struct RowRW<uint16_t, 1> {
     static constexpr int NF = 8;
-    __device__ static void load(const void *w, int64_t e, float (&v)[8]) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(w) + e);
+    typedef uint4 Raw;
+    __device__ static Raw load_raw(const void *w, int64_t e) {
+        return *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(w) + e);
+    }
+    __device__ static void unpack(const Raw &x, float (&v)[8]) {
         v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
         v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
         v[4] = __uint_as_float(x.z << 16); v[5] = __uint_as_float(x.z & 0xffff0000u);
@@ -159,15 +163,17 @@ struct RowRW<uint16_t, 1> {
 template <>
 struct RowRW<float, 0> {
     static constexpr int NF = 1;
-    __device__ static void load(const void *w, int64_t e, float (&v)[1]) { v[0] = static_cast<const float *>(w)[e]; }
+    typedef float Raw;
+    __device__ static Raw load_raw(const void *w, int64_t e) { return static_cast<const float *>(w)[e]; }
+    __device__ static void unpack(const Raw &x, float (&v)[1]) { v[0] = x; }
     __device__ static void store(void *w, int64_t e, const float (&v)[1]) { static_cast<float *>(w)[e] = v[0]; }
 };
 template <>
 struct RowRW<uint16_t, 0> {
     static constexpr int NF = 1;
-    __device__ static void load(const void *w, int64_t e, float (&v)[1]) {
-        v[0] = __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t *>(w)[e]) << 16);
-    }
+    typedef uint16_t Raw;
+    __device__ static Raw load_raw(const void *w, int64_t e) { return static_cast<const uint16_t *>(w)[e]; }
+    __device__ static void unpack(const Raw &x, float (&v)[1]) { v[0] = __uint_as_float(static_cast<uint32_t>(x) << 16); }
     __device__ static void store(void *w, int64_t e, const float (&v)[1]) {
         static_cast<uint16_t *>(w)[e] = (uint16_t)f32_to_bf16_bits(v[0]);
     }
@@ -208,10 +214,14 @@ __device__ inline void store_vec(float *g, const float (&v)[NF]) {
 // optimizer step on row k given its current values w and its summed gradient acc
 template <typename ROW, int VEC16, int G, int NC>
 __device__ inline void apply_loaded(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
-                                    float (&w)[NC][RowRW<ROW, VEC16>::NF], const int (&col)[NC],
+                                    const typename RowRW<ROW, VEC16>::Raw (&wraw)[NC], const int (&col)[NC],
                                     const bool (&col_ok)[NC], int lig) {
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
+    float w[NC][NF];   // rows are converted only now: their loads were issued together, earlier
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (col_ok[c]) RW::unpack(wraw[c], w[c]);
     const int64_t e0 = k * p.D;
     float mult = p.lr;
     if (p.adagrad) {
@@ -242,11 +252,10 @@ template <typename ROW, int VEC16, int G, int NC>
 __device__ inline void apply_row_update(const BwdParams &p, int64_t k, float (&acc)[NC][RowRW<ROW, VEC16>::NF],
                                         const int (&col)[NC], const bool (&col_ok)[NC], int lig) {
     using RW = RowRW<ROW, VEC16>;
-    constexpr int NF = RW::NF;
-    float w[NC][NF];
+    typename RW::Raw w[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++)
-        if (col_ok[c]) RW::load(p.w, k * p.D + col[c], w[c]);
+        if (col_ok[c]) w[c] = RW::load_raw(p.w, k * p.D + col[c]);
     apply_loaded<ROW, VEC16, G, NC>(p, k, acc, w, col, col_ok, lig);
 }
 
@@ -377,7 +386,8 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
         float sc[kChunk];
 #pragma unroll
         for (int u = 0; u < kChunk; u++) gp[u] = occurrence<IDX>(p, (uint32_t)s_val[q0 + (v[u] ? u : fu)], sc[u]);
-        float g[kChunk][NC][NF], w[kChunk][NC][NF];
+        float g[kChunk][NC][NF];
+        typename RW::Raw w[kChunk][NC];
         if (any_w) {
             int64_t row[kChunk];
 #pragma unroll
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
                 for (int c = 0; c < NC; c++)
                     if (col_ok[c]) {
                         load_grad<NF>(gp[u] + col[c], g[u][c]);
-                        RW::load(p.w, row[u] * p.D + col[c], w[u][c]);
+                        w[u][c] = RW::load_raw(p.w, row[u] * p.D + col[c]);
                     }
         } else {
 #pragma unroll

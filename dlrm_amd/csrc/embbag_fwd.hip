@@ -43,43 +43,48 @@ struct FwdParams {
     const int64_t *shard;  // first global row held per table (row-wise shard), or NULL
 };
 
-// 16 bytes of a row as NF floats
+// 16 bytes of a row as NF floats.  `load` only fetches (the raw register image): conversions happen
+// in `add`, so that all of a step's loads are issued before anything waits for one of them.
 template <typename ROW, int VEC16>
 struct RowLoad;
 
 template <>
 struct RowLoad<float, 1> {
     static constexpr int NF = 4;
-    __device__ static void load(const void *w, int64_t elem, float (&v)[4]) {
-        const float4 x = *reinterpret_cast<const float4 *>(static_cast<const float *>(w) + elem);
-        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    typedef float4 Raw;
+    __device__ static Raw load(const void *w, int64_t elem) {
+        return *reinterpret_cast<const float4 *>(static_cast<const float *>(w) + elem);
     }
+    __device__ static void add(float (&a)[4], const Raw &x) { a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w; }
 };
 template <>
 struct RowLoad<uint16_t, 1> {
     static constexpr int NF = 8;
-    __device__ static void load(const void *w, int64_t elem, float (&v)[8]) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(w) + elem);
-        v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
-        v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
-        v[4] = __uint_as_float(x.z << 16); v[5] = __uint_as_float(x.z & 0xffff0000u);
-        v[6] = __uint_as_float(x.w << 16); v[7] = __uint_as_float(x.w & 0xffff0000u);
+    typedef uint4 Raw;
+    __device__ static Raw load(const void *w, int64_t elem) {
+        return *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(w) + elem);
+    }
+    __device__ static void add(float (&a)[8], const Raw &x) {
+        a[0] += __uint_as_float(x.x << 16); a[1] += __uint_as_float(x.x & 0xffff0000u);
+        a[2] += __uint_as_float(x.y << 16); a[3] += __uint_as_float(x.y & 0xffff0000u);
+        a[4] += __uint_as_float(x.z << 16); a[5] += __uint_as_float(x.z & 0xffff0000u);
+        a[6] += __uint_as_float(x.w << 16); a[7] += __uint_as_float(x.w & 0xffff0000u);
     }
 };
 // element-per-lane fallback for dims / alignments the 16-byte path cannot take
 template <>
 struct RowLoad<float, 0> {
     static constexpr int NF = 1;
-    __device__ static void load(const void *w, int64_t elem, float (&v)[1]) {
-        v[0] = static_cast<const float *>(w)[elem];
-    }
+    typedef float Raw;
+    __device__ static Raw load(const void *w, int64_t elem) { return static_cast<const float *>(w)[elem]; }
+    __device__ static void add(float (&a)[1], const Raw &x) { a[0] += x; }
 };
 template <>
 struct RowLoad<uint16_t, 0> {
     static constexpr int NF = 1;
-    __device__ static void load(const void *w, int64_t elem, float (&v)[1]) {
-        v[0] = __uint_as_float(static_cast<uint32_t>(static_cast<const uint16_t *>(w)[elem]) << 16);
-    }
+    typedef uint16_t Raw;
+    __device__ static Raw load(const void *w, int64_t elem) { return static_cast<const uint16_t *>(w)[elem]; }
+    __device__ static void add(float (&a)[1], const Raw &x) { a[0] += __uint_as_float(static_cast<uint32_t>(x) << 16); }
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
 
     const int64_t start = so[0], end = so[nb];
     for (int64_t pos = start; pos < end; pos += kUnroll) {
-        float v[kUnroll][NC][NF];
+        typename RL::Raw v[kUnroll][NC];
         int bagj[kUnroll];
         bool ok[kUnroll];
 #pragma unroll
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
                     const int64_t e0 = (tbase + r) * p.D;
 #pragma unroll
                     for (int c = 0; c < NC; c++)
-                        if (col_ok[c]) RL::load(p.w, e0 + col[c], v[j][c]);
+                        if (col_ok[c]) v[j][c] = RL::load(p.w, e0 + col[c]);
                 }
             }
         }
@@ -208,10 +213,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
                 if (ok[j]) {
 #pragma unroll
                     for (int c = 0; c < NC; c++)
-                        if (col_ok[c]) {
-#pragma unroll
-                            for (int q = 0; q < NF; q++) acc[c][q] += v[j][c][q];
-                        }
+                        if (col_ok[c]) RL::add(acc[c], v[j][c]);
                 }
             }
         }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_wave_kernel(FwdParams 
     bool bad = false;
 
     for (int64_t pos = start + grp; pos < end; pos += (int64_t)NG * kUnroll) {
-        float v[kUnroll][NC][NF];
+        typename RL::Raw v[kUnroll][NC];
         bool ok[kUnroll];
 #pragma unroll
         for (int j = 0; j < kUnroll; j++) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_wave_kernel(FwdParams 
                     const int64_t e0 = (tbase + r) * p.D;
 #pragma unroll
                     for (int c = 0; c < NC; c++)
-                        if (col_ok[c]) RL::load(p.w, e0 + col[c], v[j][c]);
+                        if (col_ok[c]) v[j][c] = RL::load(p.w, e0 + col[c]);
                 }
             }
         }
@@ -289,10 +291,7 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_wave_kernel(FwdParams 
             if (ok[j]) {
 #pragma unroll
                 for (int c = 0; c < NC; c++)
-                    if (col_ok[c]) {
-#pragma unroll
-                        for (int q = 0; q < NF; q++) acc[c][q] += v[j][c][q];
-                    }
+                    if (col_ok[c]) RL::add(acc[c], v[j][c]);
             }
     }
     // combine the NG partial sums: butterfly over the lane bits above log2(G)
