@@ -139,6 +139,11 @@ def main():
     ap.add_argument("--sharding", default="table", choices=["table", "hybrid"],
                     help="N>1: whole tables per rank, or the biggest tables split by rows over all ranks")
     ap.add_argument("--row-wise-min-rows", type=int, default=20_000_000)
+    ap.add_argument("--cache-fraction", type=float, default=0.0,
+                    help="tables in pinned host DRAM behind an HBM cache of this fraction of their pages (0 = tables in HBM)")
+    ap.add_argument("--cache-rows-per-page", type=int, default=1)
+    ap.add_argument("--no-prefetch", action="store_true", help="cached mode: look ids up inside the step")
+    ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,11 +181,14 @@ def main():
     if args.sharding == "hybrid" and world > 1:
         from dlrm_amd.sharding import plan_hybrid
         plan = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows)
-    model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan)
+    cached = args.cache_fraction > 0
+    model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan,
+                 cache_fraction=args.cache_fraction if cached else None,
+                 cache_rows_per_page=args.cache_rows_per_page)
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled
-    n_batches = 4
+    n_batches = args.batches or (64 if cached else 4)
     batches = []
     for i in range(n_batches):
         dense, idx, off, labels = synthetic_batch(local_rows, Bg, cfg.lookups, cfg.dense_in, dev,
@@ -202,6 +210,8 @@ def main():
         dense, idx, off, labels, (uniq, uniq_rw) = batches[i % n_batches]
         model_ref["unique_rows"], model_ref["unique_rows_rw"] = uniq, uniq_rw
         model.load_batch(dense, labels)
+        if cached and not args.no_prefetch:
+            return model.train_step(idx, off, next_indices=batches[(i + 1) % n_batches][1])
         return model.train_step(idx, off)
 
     def barrier():
@@ -211,6 +221,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if cached:
+        model.cache.counters(reset=True)
+        cache_c0 = model.cache.counters()
     barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -269,6 +282,21 @@ def main():
             roofline["traffic"] = traffic.get(dom["op"])
     emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
 
+    cache_info = None
+    if cached:
+        c1, st = model.cache.counters(), model.cache.state()
+        hit = int((c1["hit"] - cache_c0["hit"]).sum())
+        miss = int((c1["miss"] - cache_c0["miss"]).sum())
+        page_bytes = args.cache_rows_per_page * cfg.dim * 4
+        cache_info = {"fraction": args.cache_fraction, "rows_per_page": args.cache_rows_per_page,
+                      "prefetch": not args.no_prefetch, "hit_rate_lookups": hit / max(hit + miss, 1),
+                      "pages_read_per_step": int(c1["read"].sum()) / args.steps,
+                      "pages_written_back_per_step": int(c1["write"].sum()) / args.steps,
+                      "h2d_GBps": int(c1["read"].sum()) * page_bytes / dt / 1e9,
+                      "cache_GB": st.cache_size * page_bytes / 1e9,
+                      "table_GB": sum(cfg.table_rows[t] for t in model.local_table_ids) * cfg.dim * 4 / 1e9,
+                      "error_flags": int(st.error_flags)}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_cpu_baseline
@@ -290,6 +318,7 @@ def main():
                        ("%s x%d + data-parallel MLP" % ("table-wise" if not model.Trw else
                                                         "table-wise + %d row-wise tables" % model.Trw, world))},
             "loss": float(loss.item()),
+            "cache": cache_info,
             "roofline": roofline,
             "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,
             "kernels": kernels,

@@ -79,6 +79,8 @@ class EmbeddingCache:
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             torch.cuda.synchronize()
+            self.reclaim_finish()
+            torch.cuda.synchronize()
             self.L.dlrm_cache_destroy(self.h)
             self.h = None
             self.store = []
@@ -96,12 +98,14 @@ class EmbeddingCache:
     def _stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def write(self, seed=0):
-        """embedding_table_init::write(): every table uniform [0,1)."""
+    def write(self, seed=0, table_ids=None):
+        """embedding_table_init::write(): every table uniform [0,1).  table_ids: the global id of
+        each table (its random stream is keyed by it); default 0..T-1."""
         for t, p in enumerate(self._ptrs):
             n = self.table_rows[t] * self.dim
             dt = _capi.F32 if self.pool.dtype == torch.float32 else _capi.BF16
-            check(self.L.dlrm_table_init_uniform(p, dt, C.c_int64(n), C.c_uint64((seed << 20) + 7919 * (t + 1)),
+            gid = t if table_ids is None else table_ids[t]
+            check(self.L.dlrm_table_init_uniform(p, dt, C.c_int64(n), C.c_uint64((seed << 20) + 7919 * (gid + 1)),
                                                  C.c_int64(0), self._stream()))
         torch.cuda.synchronize()
 
@@ -117,9 +121,23 @@ class EmbeddingCache:
         return rows
 
     def reclaim(self):
+        self.reclaim_finish()           # a pending first half belongs to an earlier step
         check(self.L.dlrm_cache_reclaim(self.h, self._stream()))
 
+    def reclaim_begin(self):
+        """First half of reclaim (choice of victims + asynchronous read-back of their count)."""
+        check(self.L.dlrm_cache_reclaim_begin(self.h, self._stream()))
+        self._pending = True
+
+    def reclaim_finish(self):
+        """Second half (write-back + eviction); waits for the first half's read-back only.  No lookup
+        may be queued between the two halves."""
+        if getattr(self, "_pending", False):
+            check(self.L.dlrm_cache_reclaim_finish(self.h, self._stream()))
+            self._pending = False
+
     def flush(self):
+        self.reclaim_finish()
         check(self.L.dlrm_cache_flush(self.h, self._stream()))
         torch.cuda.synchronize()
 

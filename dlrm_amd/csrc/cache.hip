@@ -33,6 +33,11 @@ namespace dlrm {
 constexpr int kMaxCacheTables = 64;
 constexpr int kAgeBins = 1024;
 constexpr int kCacheThreads = 256;
+// Workgroups of the kernels that move pages over the host link.  Their lanes spend microseconds
+// waiting for each 16-byte piece; a grid that fills the chip would hold every wave slot for that long
+// and starve the kernels of another stream (a prefetching lookup runs beside the MLP).  128 K lanes in
+// flight keep the link busy and leave most wave slots free.
+constexpr int kLinkBlocks = 512;
 constexpr int kNumCounters = 6;  // read_pages, write_pages, hit_ids, miss_ids, evicted_pages, resident_pages
 enum { C_READ = 0, C_WRITE = 1, C_HIT = 2, C_MISS = 3, C_EVICT = 4, C_RESIDENT = 5 };
 enum { S_HEAD = 0, S_TAIL, S_PAGE_COUNT, S_CACHE_SIZE, S_N_MISS, S_N_CAND, S_ERROR, S_EPOCH, S_PASSES, S_N_ASSIGNED,
@@ -82,6 +87,9 @@ struct dlrm_cache {
     void *sort_tmp;
     size_t sort_tmp_bytes;
     int64_t *h_scalars;      // pinned staging for scalar read-back
+    int64_t *h_reclaim;      // pinned copy of the scalars taken by reclaim_begin
+    hipEvent_t reclaim_ev;   // recorded behind that copy
+    bool reclaim_pending;
     bool owns_pool;
 };
 
@@ -562,6 +570,9 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
         c->owns_pool = true;
         if (!rc) rc = dev_alloc(&d.data, (size_t)d.S * (size_t)page_bytes);
     }
+    if (!rc && (hipHostMalloc(reinterpret_cast<void **>(&c->h_reclaim), sizeof(int64_t) * S_COUNT, 0) != hipSuccess ||
+                hipEventCreateWithFlags(&c->reclaim_ev, hipEventDisableTiming) != hipSuccess))
+        rc = set_error(DLRM_ERR_NOMEM, "reclaim staging allocation failed");
     if (!rc && hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), sizeof(int64_t) * S_COUNT, 0) != hipSuccess)
         rc = set_error(DLRM_ERR_NOMEM, "hipHostMalloc failed");
     if (rc) { dlrm_cache_destroy(c); return rc; }
@@ -591,6 +602,8 @@ extern "C" int dlrm_cache_destroy(dlrm_cache *c) {
     if (c->owns_pool) (void)hipFree(d.data);
     (void)hipFree(c->sort_tmp);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->h_reclaim) (void)hipHostFree(c->h_reclaim);
+    if (c->reclaim_ev) (void)hipEventDestroy(c->reclaim_ev);
     delete c;
     return DLRM_OK;
 }
@@ -657,7 +670,7 @@ extern "C" int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_d
     DLRM_HIP(rocprim::radix_sort_keys(c->sort_tmp, tmp, c->d.miss, c->d.miss_sorted, (size_t)n, 0u, (unsigned)bits, s,
                                       false));
     hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d);
-    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(kCacheThreads), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(fill_kernel, dim3(kLinkBlocks), dim3(kCacheThreads), 0, s, c->g, c->d);
     if (idx_dtype == DLRM_I64)
         hipLaunchKernelGGL(translate_kernel<int64_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
                            static_cast<const int64_t *>(d_ids), n, static_cast<int64_t *>(d_rows_out));
@@ -669,17 +682,29 @@ extern "C" int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_d
     return DLRM_OK;
 }
 
-extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
+extern "C" int dlrm_cache_reclaim_begin(dlrm_cache *c, dlrm_stream_t stream) {
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(!c->reclaim_pending, "dlrm_cache_reclaim_begin called twice without dlrm_cache_reclaim_finish");
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(plan_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
     hipLaunchKernelGGL(age_hist_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
     hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(64), 0, s, c->g, c->d);
     hipLaunchKernelGGL(collect_candidates_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
     DLRM_LAUNCH_CHECK();
-    // the candidate count decides the size of the sort: one small read-back per reclaim
-    if (int rc = read_scalars(c, s)) return rc;
-    const int64_t passes = c->h_scalars[S_PASSES], n_cand = c->h_scalars[S_N_CAND];
+    // the candidate count decides the size of the sort: one small read-back, waited for in _finish
+    DLRM_HIP(hipMemcpyAsync(c->h_reclaim, c->d.scalars, sizeof(int64_t) * S_COUNT, hipMemcpyDeviceToHost, s));
+    DLRM_HIP(hipEventRecord(c->reclaim_ev, s));
+    c->reclaim_pending = true;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(c->reclaim_pending, "dlrm_cache_reclaim_finish without dlrm_cache_reclaim_begin");
+    hipStream_t s = as_stream(stream);
+    DLRM_HIP(hipEventSynchronize(c->reclaim_ev));
+    c->reclaim_pending = false;
+    const int64_t passes = c->h_reclaim[S_PASSES], n_cand = c->h_reclaim[S_N_CAND];
     if (passes == 0) return DLRM_OK;
     if (n_cand > 0) {
         size_t tmp = 0;
@@ -692,7 +717,7 @@ extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
         int32_t *cand_pos = c->d.cand_val;  // the unsorted value buffer is free once the sort is done
         hipLaunchKernelGGL(rank_victims_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
-        hipLaunchKernelGGL(writeback_victims_kernel, dim3(4096), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
+        hipLaunchKernelGGL(writeback_victims_kernel, dim3(kLinkBlocks), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
         hipLaunchKernelGGL(evict_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
@@ -700,6 +725,11 @@ extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
     hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
+    if (int rc = dlrm_cache_reclaim_begin(c, stream)) return rc;
+    return dlrm_cache_reclaim_finish(c, stream);
 }
 
 extern "C" int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream) {

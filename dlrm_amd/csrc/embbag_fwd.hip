@@ -189,8 +189,10 @@ __global__ __launch_bounds__(kFwdThreads) void embbag_fwd_group_kernel(FwdParams
                 while (look >= look_next_table) {
                     t_look++;
                     look_next_table += p.B;
-                    tbase = p.tro[t_look];
-                    trows = p.tro[t_look + 1] - tbase;
+                    if (p.tro) {
+                        tbase = p.tro[t_look];
+                        trows = p.tro[t_look + 1] - tbase;
+                    }
                     if (p.shard) sbase = p.shard[t_look];
                 }
                 bagj[j] = look;
@@ -350,8 +352,8 @@ int validate_embbag(const dlrm_embbag *e) {
     DLRM_REQUIRE(e->row_dtype == DLRM_F32 || e->row_dtype == DLRM_BF16, "row_dtype %d", e->row_dtype);
     DLRM_REQUIRE(e->idx_dtype == DLRM_I32 || e->idx_dtype == DLRM_I64, "idx_dtype %d", e->idx_dtype);
     DLRM_REQUIRE(e->pooling == DLRM_POOL_SUM || e->pooling == DLRM_POOL_MEAN, "pooling %d", e->pooling);
-    DLRM_REQUIRE(e->num_tables == 1 || e->d_table_row_offsets != nullptr,
-                 "d_table_row_offsets is required when num_tables > 1");
+    DLRM_REQUIRE(e->d_table_row_offsets != nullptr || e->d_shard_row_begin == nullptr,
+                 "row-wise shards need d_table_row_offsets");
     DLRM_REQUIRE(e->d_weight != nullptr || e->total_rows == 0, "d_weight is NULL");
     DLRM_REQUIRE(e->d_offsets != nullptr || e->batch == 0, "d_offsets is NULL");
     DLRM_REQUIRE(e->d_indices != nullptr || e->n_indices == 0, "d_indices is NULL");

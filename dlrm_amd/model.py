@@ -172,11 +172,17 @@ class MLPStack:
 
 class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
-                 seed=0, process_group=None, init_tables=True, overlap=None):
+                 seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
+                 cache_rows_per_page=1):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
-        concurrent HBM traffic buys nothing: measured 0.2 %)."""
+        concurrent HBM traffic buys nothing: measured 0.2 %).
+        cache_fraction: keep the tables in pinned host DRAM and only this fraction of their pages in
+        an HBM cache (dlrm_amd.cache.EmbeddingCache, the reference's `class cache`); every step looks
+        its ids up (misses are filled over the host link), pools and updates rows inside the cache's
+        slot pool and reclaims down to the capacity.  `train_step(..., next_indices=...)` looks the next
+        batch up on a second stream while this one computes."""
         _capi.lib()  # fail loudly if the HIP library is missing
         self.cfg, self.B, self.rank, self.world, self.pg = cfg, batch, rank, world, process_group
         self.Bg = batch * world
@@ -208,7 +214,29 @@ class DLRM:
         self.total_rows = tro[-1]
         self.table_row_offsets = torch.tensor(tro, dtype=torch.int64, device=dev)
         wdtype = torch.bfloat16 if cfg.row_dtype == "bf16" else torch.float32
-        self.weight = torch.empty((max(self.total_rows, 1), D), dtype=wdtype, device=dev)
+        self.cache = None
+        if cache_fraction is not None:
+            if self.rw_tables or cfg.emb_optimizer != "sgd":
+                raise ValueError("the cached mode supports whole tables and the SGD row update")
+            from .cache import EmbeddingCache
+            esz = 2 if cfg.row_dtype == "bf16" else 4
+            rpp = cache_rows_per_page
+            pages = sum((r + rpp - 1) // rpp for r in rows)
+            cache_pages = max(int(pages * cache_fraction), 1)
+            # a lookup can bring in one page per id of the global batch on top of the capacity
+            headroom = min(pages, self.Tl * self.Bg * cfg.lookups)
+            self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
+                                        row_dtype=wdtype, device=dev)
+            if init_tables:
+                self.cache.write(seed, table_ids=self.local_table_ids)
+            self.weight = self.cache.pool
+            self.table_row_offsets = None          # ids are translated to rows of the shared slot pool
+            self._rows = None
+            self.lookup_stream = torch.cuda.Stream(device=dev)
+            init_tables = False
+            assert esz * D * rpp % 16 == 0
+        else:
+            self.weight = torch.empty((max(self.total_rows, 1), D), dtype=wdtype, device=dev)
         if init_tables and self.total_rows:
             # every table is its own stream of uniform [0,1) values, keyed by the GLOBAL
             # table id, so a sharded model holds the same numbers as a single-GPU one
@@ -288,16 +316,38 @@ class DLRM:
         """Descriptor arguments for the whole tables of this rank: the first Tl tables of the
         local order (offsets are table-major and absolute, so a prefix is a valid CSR)."""
         n = self.Tl * self.Bg
+        tro = None if self.table_row_offsets is None else self.table_row_offsets[:self.Tl + 1]
         return dict(weight=self.weight, indices=indices, offsets=offsets[:n + 1], batch=self.Bg, num_tables=self.Tl,
-                    table_row_offsets=self.table_row_offsets[:self.Tl + 1], pooling=self.pooling,
-                    include_last_offset=True, error_flag=self.err_flag)
+                    table_row_offsets=tro, pooling=self.pooling, include_last_offset=True, error_flag=self.err_flag)
 
-    def _rw_kwargs(self, indices, offsets):
-        """Same for the row ranges this rank holds of the row-wise tables."""
-        n = self.Tl * self.Bg
-        return dict(weight=self.weight, indices=indices, offsets=offsets[n:], batch=self.Bg, num_tables=self.Trw,
-                    table_row_offsets=self.table_row_offsets[self.Tl:], pooling=self.pooling,
-                    include_last_offset=True, error_flag=self.err_flag, shard_row_begin=self.shard_row_begin)
+    # ---------------------------------------------------------- cached tables
+
+    def _table_pos(self, indices, table_pos):
+        if table_pos is not None:
+            return [int(x) for x in table_pos]
+        n = indices.numel()
+        if n % max(self.Tl, 1):
+            raise ValueError("ragged batches need table_pos (where each table's ids start)")
+        return [t * (n // self.Tl) for t in range(self.Tl + 1)]
+
+    def lookup(self, indices, table_pos=None):
+        """create_emb's gather (src/dlrmtest.cpp:53-86): slot-pool row of every id of the batch."""
+        return self.cache.get_emb_vectors(indices, self._table_pos(indices, table_pos))
+
+    def _pipeline_next(self, next_indices, next_table_pos):
+        """Cache work that runs beside this step's kernels, on the lookup stream: the second half of the
+        previous step's reclaim, the lookup of the NEXT batch (its misses cross the host link while this
+        batch computes), then -- once this step's row update is done -- the first half of this step's
+        reclaim.  The host only waits for a read-back that finished a step ago."""
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.lookup_stream):
+            self.cache.reclaim_finish()
+            rows = self.lookup(next_indices, next_table_pos)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._rows = (next_indices, rows, ev)
+            self.lookup_stream.wait_stream(main)        # this step's rows are updated
+            self.cache.reclaim_begin()
 
     def _reduce_scatter_batch(self, out, inp):
         """out [B, C] = sum over ranks of their inp [Bg, C] rows of this rank's batch slice."""
@@ -398,12 +448,31 @@ class DLRM:
         self.top.forward(self.inter[:, :cfg.top_in], self.top_acts)
         return self.pred
 
-    def train_step(self, indices, offsets):
+    def train_step(self, indices, offsets, next_indices=None, table_pos=None, next_table_pos=None):
         """One iteration of the reference's loop body (src/dlrmtest.cpp:505-535):
         forward, loss, backward, optimizer step on every parameter, sparse
         row update.  Returns the device scalar holding this rank's share of the
-        global-mean loss."""
+        global-mean loss.  Cached tables: ids are looked up first (or were prefetched by the
+        previous call through next_indices) and the cache is reclaimed at the end
+        (reclaim_emb_cache, src/dlrmtest.cpp:397-412, :494)."""
         cfg = self.cfg
+        pipelined = False
+        if self.cache is not None:
+            if self._rows is not None and self._rows[0] is indices:
+                _, rows, ev = self._rows
+                torch.cuda.current_stream().wait_event(ev)
+                rows.record_stream(torch.cuda.current_stream())   # allocated on the lookup stream
+            else:
+                main = torch.cuda.current_stream()
+                self.lookup_stream.wait_stream(main)
+                with torch.cuda.stream(self.lookup_stream):       # not looked up ahead: do it now
+                    self.cache.reclaim_finish()
+                    rows = self.lookup(indices, table_pos)
+                main.wait_stream(self.lookup_stream)
+                rows.record_stream(main)
+            self._rows = None
+            pipelined = next_indices is not None
+            indices = rows
         self.forward(indices, offsets)
         if cfg.loss == "bce":
             ops.loss_bce_logits(self.pred.view(-1), self.labels, loss=self.loss, dlogit=self.dpred.view(-1),
@@ -441,4 +510,12 @@ class DLRM:
             import torch.distributed as dist
             dist.all_reduce(self.grads, group=self.pg)
         ops.sgd_step_(self.params, self.grads, cfg.lr)
+        if self.cache is not None:
+            if pipelined:
+                self._pipeline_next(next_indices, next_table_pos)
+            else:
+                self.lookup_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.lookup_stream):
+                    self.cache.reclaim()
+                torch.cuda.current_stream().wait_stream(self.lookup_stream)
         return self.loss

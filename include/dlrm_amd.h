@@ -88,8 +88,10 @@ int dlrm_copy_2d(float *d_dst, int64_t dst_ld, const float *d_src, int64_t src_l
  */
 typedef struct dlrm_embbag {
     void *d_weight;                     /* [total_rows, dim], row_dtype */
-    const int64_t *d_table_row_offsets; /* device int64[T+1]; NULL when T == 1 (one table, */
-                                        /* rows [0, total_rows)) */
+    const int64_t *d_table_row_offsets; /* device int64[T+1]: table t holds rows [o[t], o[t+1]) of d_weight. */
+                                        /* NULL: every table addresses the whole row space [0, total_rows) */
+                                        /* -- one table, or indices that are already rows of a shared pool */
+                                        /* (the slot rows dlrm_cache_lookup returns) */
     int64_t total_rows;
     int32_t num_tables;
     int32_t dim;
@@ -336,6 +338,15 @@ int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_dtype, const
  * back to the store.  Reads one small scalar block back (synchronises).
  */
 int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream);
+/*
+ * The same in two halves, so that the host never waits for the device in a pipelined loop (the
+ * reference's reclaim_emb_cache is synchronous, src/dlrmtest.cpp:397-403).  _begin queues the choice of
+ * victims and an asynchronous read-back of their count; _finish waits for that read-back only, then
+ * queues write-back and eviction.  Between the two the host may queue anything that does not call into
+ * this cache.  Both halves go to the same stream.
+ */
+int dlrm_cache_reclaim_begin(dlrm_cache *c, dlrm_stream_t stream);
+int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream);
 /* Write every resident page back to the store without dropping it. */
 int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream);
 /*

@@ -22,8 +22,9 @@ def test_library_exports_every_declared_symbol():
 def test_invalid_descriptor_is_rejected_without_launch():
     L = _capi.lib()
     d = _capi.EmbBagDesc()
-    d.num_tables, d.dim, d.batch = 2, 16, 4  # two tables but no row offsets
+    d.num_tables, d.dim, d.batch = 2, 16, 4
     d.row_dtype, d.idx_dtype = _capi.F32, _capi.I64
+    d.d_shard_row_begin = 256                # row-wise shards but no row offsets (never dereferenced)
     rc = L.dlrm_embbag_forward(C.byref(d), None, C.c_int64(32), None)
     assert rc == 1
     assert b"d_table_row_offsets" in L.dlrm_last_error()

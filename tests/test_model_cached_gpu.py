@@ -1,0 +1,64 @@
+"""Training with the tables in pinned host DRAM behind the HBM page cache (DLRM(cache_fraction=...)):
+every step looks its ids up, pools and updates rows inside the slot pool, reclaims; the next batch is
+looked up on a second stream meanwhile.  Losses, predictions and -- after a flush -- the backing store
+must match the oracle's step on whole tables (float32, 1e-5 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_model import make_batch, oracle_train_step
+from tests.test_embbag_forward_gpu import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows_per_page", [1, 4])
+@pytest.mark.parametrize("prefetch", [False, True])
+@pytest.mark.parametrize("kind", ["dot", "cat"])
+def test_cached_training_matches_oracle(oracle, rows_per_page, prefetch, kind):
+    from dlrm_amd.model import DLRM, DLRMConfig
+    if kind == "dot":
+        cfg = DLRMConfig(table_rows=[600, 500, 1000, 640], dim=16, dense_in=13, bottom=[32, 16], top=[24, 1], lr=0.05,
+                         lookups=2)
+    else:
+        cfg = DLRMConfig(table_rows=[4000, 3000, 7000], dim=8, dense_in=6, bottom=[16, 8], top=[12, 1], interaction="cat",
+                         loss="mse", final_relu=True, pooling="mean", lookups=3, lr=0.02)
+    B = 32
+    # capacities small enough that pages are evicted within the 8 steps, large enough that no page of
+    # the running (or prefetched) batch is among the victims
+    m = DLRM(cfg, B, seed=5, cache_fraction=0.5 if kind == "dot" else (0.1 if rows_per_page == 1 else 0.35),
+             cache_rows_per_page=rows_per_page)
+    if kind == "cat":
+        for b in m.bottom.b + m.top.b:
+            b.abs_()
+    T = cfg.num_tables
+    tables = [oracle.table_init_uniform(r * cfg.dim, (5 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+              for t, r in enumerate(cfg.table_rows)]
+    Ws = [w.cpu().numpy().copy() for w in m.bottom.W + m.top.W]
+    bs = [b.cpu().numpy().copy() for b in m.bottom.b + m.top.b]
+    rng = np.random.default_rng(31)
+    n_steps = 8
+    host = [make_batch(rng, cfg, B) for _ in range(n_steps)]
+    dev = [(torch.from_numpy(d).cuda(), torch.from_numpy(i.astype(np.int32)).cuda(),
+            torch.from_numpy(o.astype(np.int32)).cuda(), torch.from_numpy(l).cuda()) for d, i, o, l in host]
+    for s in range(n_steps):
+        dense, idx, off, labels = host[s]
+        d_dense, d_idx, d_off, d_labels = dev[s]
+        m.load_batch(d_dense, d_labels)
+        nxt = dev[s + 1][1] if (prefetch and s + 1 < n_steps) else None
+        loss = m.train_step(d_idx, d_off, next_indices=nxt)
+        torch.cuda.synchronize()
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                               cfg.lr)
+        assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        st = m.cache.state()
+        assert st.error_flags == 0 and int(m.err_flag.item()) == 0
+        if not prefetch:    # (pipelined: the second half of this step's reclaim is queued by the next step)
+            assert st.page_count <= st.cache_size + T * 8      # reclaimed down to the capacity (+ one group per table)
+    cnt = m.cache.counters()
+    assert cnt["miss"].sum() > 0 and cnt["hit"].sum() > 0 and cnt["evicted"].sum() > 0
+    m.cache.flush()
+    for t in range(T):
+        assert rel_err(np.asarray(m.cache.store[t]), tables[t]) <= 1e-5
+    m.cache.close()
