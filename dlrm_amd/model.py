@@ -349,6 +349,13 @@ class DLRM:
             self.lookup_stream.wait_stream(main)        # this step's rows are updated
             self.cache.reclaim_begin()
 
+    def _rw_kwargs(self, indices, offsets):
+        """Descriptor arguments for the row ranges this rank holds of the row-wise tables."""
+        n = self.Tl * self.Bg
+        return dict(weight=self.weight, indices=indices, offsets=offsets[n:], batch=self.Bg, num_tables=self.Trw,
+                    table_row_offsets=self.table_row_offsets[self.Tl:], pooling=self.pooling,
+                    include_last_offset=True, error_flag=self.err_flag, shard_row_begin=self.shard_row_begin)
+
     def _reduce_scatter_batch(self, out, inp):
         """out [B, C] = sum over ranks of their inp [Bg, C] rows of this rank's batch slice."""
         import torch.distributed as dist
