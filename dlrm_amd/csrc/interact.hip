@@ -110,11 +110,12 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = D + 4;
-    float *sx = smem + (size_t)wave * (kFP * ld + kFP * kSLd);
-    float *ss = sx + kFP * ld;
-    for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;
+    // per wave: the sample [F][ld] and the gradient tile [F][kSLd] (+ one spare cell); only F rows
+    // are kept (operand rows F..31 are masked at the reads), which lets two workgroups share a CU
+    float *sx = smem + (size_t)wave * (F * ld + F * kSLd + 4);
+    float *ss = sx + F * ld;
     // the gradient tile only ever has entries (i,j), (j,i) with j < i < F written: zero it once
-    for (int i = lane; i < kFP * kSLd; i += 64) ss[i] = 0.f;
+    for (int i = lane; i < F * kSLd + 4; i += 64) ss[i] = 0.f;
     const int n_pairs = F * (F - 1) / 2;
     const int n4 = F * D / 4;
     const int row = lane & 31, h = lane >> 5;
@@ -136,9 +137,10 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
     int sij[kMaxPairs], sji[kMaxPairs];
 #pragma unroll
     for (int u = 0; u < kMaxPairs; u++) {
-        const int i = pij[u] >= 0 ? pij[u] >> 8 : kFP - 1, j = pij[u] >= 0 ? pij[u] & 255 : kFP - 1;
-        sij[u] = i * kSLd + j;     // (31,31) is never read as a gradient: F <= 32 rows, row 31 pairs only with j < 31
-        sji[u] = j * kSLd + i;
+        const bool real = pij[u] >= 0;
+        const int i = real ? pij[u] >> 8 : 0, j = real ? pij[u] & 255 : 0;
+        sij[u] = real ? i * kSLd + j : F * kSLd;     // lanes past the last pair write the spare cell
+        sji[u] = real ? j * kSLd + i : F * kSLd;
     }
     int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
     int lds_off[NV];
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
         // A fragments of S' = S + S^T: 4 chunks of 8 reduction (feature) indices
         float4 fa[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) fa[q] = *reinterpret_cast<const float4 *>(ss + row * kSLd + q * 8 + h * 4);
+        for (int q = 0; q < 4; q++)   // rows >= F only feed output rows that are never stored
+            fa[q] = *reinterpret_cast<const float4 *>(ss + (row < F ? row : F - 1) * kSLd + q * 8 + h * 4);
         float *gx = dx + b * F * D;
         for (int d0 = 0; d0 < D; d0 += 32) {
             const int d = d0 + row;
@@ -186,24 +189,36 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
                 const float a[4] = {fa[q].x, fa[q].y, fa[q].z, fa[q].w};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float bv = d_ok ? sx[(q * 8 + h * 4 + j) * ld + d] : 0.f;
+                    const int k = q * 8 + h * 4 + j;
+                    const float xv = sx[(k < F ? k : F - 1) * ld + (d_ok ? d : 0)];
+                    const float bv = (d_ok && k < F) ? xv : 0.f;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc, 0, 0, 0);
                 }
             }
+            // The 32 x 32 block of dX goes back into the columns of the staged sample it was computed
+            // from: this lane read rows 4h..4h+3 (+8, +16, +24) of column d as B operands and writes
+            // exactly those rows, so no other lane's operand is disturbed.  The whole sample then
+            // leaves with 16-byte stores (a row per register would be 4-byte stores).
             if (d_ok) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (i < F) {
-                        float v = acc[r];
-                        if (i == 0) {
-                            v += go[d];
-                            if (relu_mask0 && !(sx[d] > 0.f)) v = 0.f;
-                        }
-                        gx[i * D + d] = v;
+                    if (i >= F) continue;
+                    float v = acc[r];
+                    if (i == 0) {
+                        v += go[d];
+                        if (relu_mask0 && !(sx[d] > 0.f)) v = 0.f;
                     }
+                    sx[i * ld + d] = v;
                 }
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const int idx = u < NV - 1 ? lane + 64 * u : last_idx;
+            reinterpret_cast<f32x4 *>(gx)[idx] = *reinterpret_cast<const f32x4 *>(sx + lds_off[u]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -255,7 +270,8 @@ extern "C" int dlrm_interact_dot_backward(const float *d_x, const float *d_dout,
     if (B == 0) return DLRM_OK;
     DLRM_REQUIRE(d_dout != nullptr && d_dx != nullptr && dout_ld >= D + F * (F - 1) / 2,
                  "dout/dx is NULL or dout_ld too small");
-    const size_t lds = sizeof(float) * kIntWaves * (kFP * (D + 4) + kFP * kSLd);
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_dx) % 16 == 0, "dx must be 16-byte aligned");
+    const size_t lds = sizeof(float) * kIntWaves * ((size_t)F * (D + 4) + F * kSLd + 4);
     const int64_t want = ceil_div(B, kIntWaves);
     const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
     const int nv = (F * D / 4 + 63) / 64;
