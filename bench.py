@@ -105,6 +105,10 @@ def install_timers(ops, model_ref):
         B, F, D = x.shape
         return B * (2 * F * D + D + F * (F - 1) // 2) * 4
 
+    t.work = {"linear_forward": (gemm_flops_fwd, "mfma"), "linear_backward_data": (gemm_flops_bwd_data, "mfma"),
+              "linear_backward_weight": (gemm_flops_bwd_weight, "mfma"), "embbag_forward": (emb_fwd_bytes, "hbm"),
+              "embbag_backward_update": (emb_bwd_bytes, "hbm"), "interact_dot_forward": (inter_fwd_bytes, "hbm"),
+              "interact_dot_backward": (inter_bwd_bytes, "hbm")}
     t.wrap(ops, "linear_forward", gemm_flops_fwd, "mfma")
     t.wrap(ops, "linear_backward_data", gemm_flops_bwd_data, "mfma")
     t.wrap(ops, "linear_backward_weight", gemm_flops_bwd_weight, "mfma")
@@ -144,6 +148,8 @@ def main():
     ap.add_argument("--cache-rows-per-page", type=int, default=1)
     ap.add_argument("--no-prefetch", action="store_true", help="cached mode: look ids up inside the step")
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every operator from Python instead of replaying the recorded step (dlrm_plan)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,7 +190,7 @@ def main():
     cached = args.cache_fraction > 0
     model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan,
                  cache_fraction=args.cache_fraction if cached else None,
-                 cache_rows_per_page=args.cache_rows_per_page)
+                 cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager)
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled
@@ -226,10 +232,15 @@ def main():
         cache_c0 = model.cache.counters()
     barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = args.eager
+    if not args.eager:
+        model._plan.enable_timing(args.steps)      # event pairs around every recorded entry, on its stream
+    uniq_sum = [0, 0]
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        uniq_sum[0] += model_ref["unique_rows"]
+        uniq_sum[1] += model_ref["unique_rows_rw"]
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -246,6 +257,19 @@ def main():
 
     # per-kernel-class accounting from the events recorded inside the timed steps
     summ = timer.summary()
+    if not args.eager:
+        # the recorded step timed itself: milliseconds per entry summed over the timed replays
+        model_ref["unique_rows"] = uniq_sum[0] / args.steps
+        model_ref["unique_rows_rw"] = uniq_sum[1] / args.steps
+        ms, runs = model._plan.collect_timing()
+        for i, (name, a, kw) in enumerate(model._plan.meta):
+            if name not in timer.work or runs[i] == 0:
+                continue
+            fn, kind = timer.work[name]
+            d = summ.setdefault(name, {"ms": 0.0, "work": 0.0, "launches": 0, "kind": kind})
+            d["ms"] += ms[i]
+            d["work"] += fn(*a, **kw) * runs[i]
+            d["launches"] += runs[i]
     kernels = []
     for name, d in summ.items():
         sec = d["ms"] * 1e-3
@@ -314,6 +338,8 @@ def main():
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
                        "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
                        if gemm_mode == 1 else "float32 MFMA",
+                       "launch": "eager (one Python call per operator)" if args.eager else
+                       "recorded step replayed through dlrm_plan_run",
                        "parallelism": "single GPU" if world == 1 else
                        ("%s x%d + data-parallel MLP" % ("table-wise" if not model.Trw else
                                                         "table-wise + %d row-wise tables" % model.Trw, world))},

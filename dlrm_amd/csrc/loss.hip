@@ -46,8 +46,12 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const float *__restr
             if (i >= n) break;
             float g;
             if constexpr (BCE) {
-                a += fmaxf(x[u], 0.f) - x[u] * t[u] + log1pf(expf(-fabsf(x[u])));
-                g = (1.0f / (1.0f + expf(-x[u])) - t[u]) * inv_n;
+                // sigmoid(x) - t without cancellation when the prediction saturates towards its label
+                // (1/(1+e^-x) rounds to exactly 1 from x = 17 on, yet the gradient there is e^-x)
+                const float e = expf(-fabsf(x[u]));
+                const float r = e / (1.0f + e);                       // sigmoid(-|x|)
+                a += fmaxf(x[u], 0.f) - x[u] * t[u] + log1pf(e);
+                g = (x[u] >= 0.f ? (1.0f - t[u]) - r : r - t[u]) * inv_n;
             } else {
                 const float d = x[u] - t[u];
                 a += d * d;

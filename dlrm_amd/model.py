@@ -173,7 +173,7 @@ class MLPStack:
 class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
                  seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
-                 cache_rows_per_page=1):
+                 cache_rows_per_page=1, replay=False):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
@@ -289,6 +289,9 @@ class DLRM:
         self.loss = torch.zeros(1, **f32)
         self.ws_dense = None
         self.ws_sparse = None
+        self.replay = bool(replay) and self.dev.type == "cuda"
+        self._plan, self._plan_items, self._plan_key = None, None, None
+        self.plan_timing_runs = 0       # > 0: the recorded step times every entry (bench.py)
         # The EmbeddingBag kernels (and, sharded, their exchanges) are HBM / link bound, the bottom MLP
         # is matrix-pipe bound and the two touch different columns of `feat` / `dfeat`: they can run
         # concurrently, the embedding side on a second HIP stream.
@@ -365,70 +368,187 @@ class DLRM:
         else:
             dist.reduce_scatter_tensor(out, inp, group=self.pg)
 
-    def embedding_forward(self, indices, offsets):
+    # The step is written once, as a schedule: a list of (kind, stream, fn) items.
+    #   ("ops",  stream, fn)   fn() calls dlrm_amd.ops operators only (launched now, or recorded
+    #                          into a dlrm_plan and replayed as one C call)
+    #   ("host", stream, fn)   fn() is host work issued on that stream: the collectives
+    #   ("wait", a, b)         stream a waits for everything queued on stream b
+    # Streams are named "main" (the caller's) and "emb" (the second stream of the embedding side, or
+    # the caller's when there is no overlap).
+
+    def _emb_forward_items(self, indices, offsets):
         """emb::forward (src/dlrmtest.cpp:170-206) for this rank's tables over the
         global batch, then the exchange that leaves feat[:, emb_col0:] holding
         the pooled vectors of ALL tables for the local batch."""
         D, B = self.cfg.dim, self.B
+        items = []
         if self.world == 1:
-            out = self.feat[:, self.emb_col0:]
-            ops.embbag_forward(out=out, out_ld=self.feat.stride(0), **self._emb_kwargs(indices, offsets))
-            return
+            def pool():
+                ops.embbag_forward(out=self.feat[:, self.emb_col0:], out_ld=self.feat.stride(0),
+                                   **self._emb_kwargs(indices, offsets))
+            return [("ops", "emb", pool)]
         import torch.distributed as dist
-        if self.Tl:
-            ops.embbag_forward(out=self.a2a_send, out_ld=self.Tl * D, **self._emb_kwargs(indices, offsets))
         n_send, n_recv = self.Bg * self.Tl * D, B * self.plan.n_table_wise * D   # exact sizes (buffers hold >= 1 element)
-        dist.all_to_all_single(self.a2a_recv[:n_recv], self.a2a_send[:n_send], self.recv_splits, self.send_splits,
-                               group=self.pg)
-        o = 0
-        for j in range(self.world):
-            first, cnt = self.plan.feature_slot(j)
-            if cnt:
-                blk = self.a2a_recv[o:o + B * cnt * D].view(B, cnt * D)
-                c0 = self.emb_col0 + first * D
-                ops.copy_2d_(self.feat[:, c0:c0 + cnt * D], blk)
-            o += B * cnt * D
-        if self.Trw:
-            ops.embbag_forward(out=self.rw_part, out_ld=self.Trw * D, **self._rw_kwargs(indices, offsets))
-            self._reduce_scatter_batch(self.rw_local, self.rw_part)
-            c0 = self.emb_col0 + self.plan.n_table_wise * D
-            ops.copy_2d_(self.feat[:, c0:c0 + self.Trw * D], self.rw_local)
+        if self.Tl:
+            items.append(("ops", "emb", lambda: ops.embbag_forward(out=self.a2a_send, out_ld=self.Tl * D,
+                                                                   **self._emb_kwargs(indices, offsets))))
+        items.append(("host", "emb", lambda: dist.all_to_all_single(
+            self.a2a_recv[:n_recv], self.a2a_send[:n_send], self.recv_splits, self.send_splits, group=self.pg)))
 
-    def embedding_backward_update(self, indices, offsets):
+        def unpack():
+            o = 0
+            for j in range(self.world):
+                first, cnt = self.plan.feature_slot(j)
+                if cnt:
+                    blk = self.a2a_recv[o:o + B * cnt * D].view(B, cnt * D)
+                    c0 = self.emb_col0 + first * D
+                    ops.copy_2d_(self.feat[:, c0:c0 + cnt * D], blk)
+                o += B * cnt * D
+        if self.plan.n_table_wise:
+            items.append(("ops", "emb", unpack))
+        if self.Trw:
+            c0 = self.emb_col0 + self.plan.n_table_wise * D
+            items.append(("ops", "emb", lambda: ops.embbag_forward(out=self.rw_part, out_ld=self.Trw * D,
+                                                                   **self._rw_kwargs(indices, offsets))))
+            items.append(("host", "emb", lambda: self._reduce_scatter_batch(self.rw_local, self.rw_part)))
+            items.append(("ops", "emb", lambda: ops.copy_2d_(self.feat[:, c0:c0 + self.Trw * D], self.rw_local)))
+        return items
+
+    def _emb_backward_items(self, indices, offsets):
         """autograd of embedding_bag + optimizer step + write-back
         (src/dlrmtest.cpp:531-535) fused: gradients of the pooled vectors go
         back to the owning ranks and are applied to the rows."""
         D, B = self.cfg.dim, self.B
         cfg = self.cfg
-        kw = dict(optimizer=_capi.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else _capi.OPT_SGD,
-                  lr=cfg.lr, eps=cfg.eps, opt_state=self.opt_state, workspace=self.ws_sparse)
+
+        def update(kwargs_fn, grad, grad_ld):
+            def run():
+                self.ws_sparse = ops.embbag_backward_update(
+                    grad=grad, grad_ld=grad_ld, workspace=self.ws_sparse, lr=cfg.lr, eps=cfg.eps,
+                    opt_state=self.opt_state,
+                    optimizer=_capi.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else _capi.OPT_SGD,
+                    **kwargs_fn(indices, offsets))
+            return run
         if self.world == 1:
-            grad = self.dfeat[:, self.emb_col0:]
-            self.ws_sparse = ops.embbag_backward_update(grad=grad, grad_ld=self.dfeat.stride(0),
-                                                        **self._emb_kwargs(indices, offsets), **kw)
-            return
+            return [("ops", "emb", update(self._emb_kwargs, self.dfeat[:, self.emb_col0:], self.dfeat.stride(0)))]
         import torch.distributed as dist
-        o = 0
-        for j in range(self.world):
-            first, cnt = self.plan.feature_slot(j)
-            if cnt:
-                blk = self.g_send[o:o + B * cnt * D].view(B, cnt * D)
-                c0 = self.emb_col0 + first * D
-                ops.copy_2d_(blk, self.dfeat[:, c0:c0 + cnt * D])
-            o += B * cnt * D
+        items = []
+
+        def pack():
+            o = 0
+            for j in range(self.world):
+                first, cnt = self.plan.feature_slot(j)
+                if cnt:
+                    blk = self.g_send[o:o + B * cnt * D].view(B, cnt * D)
+                    c0 = self.emb_col0 + first * D
+                    ops.copy_2d_(blk, self.dfeat[:, c0:c0 + cnt * D])
+                o += B * cnt * D
         n_send, n_recv = self.Bg * self.Tl * D, B * self.plan.n_table_wise * D
-        dist.all_to_all_single(self.g_recv[:n_send], self.g_send[:n_recv], self.send_splits, self.recv_splits,
-                               group=self.pg)
+        if self.plan.n_table_wise:
+            items.append(("ops", "emb", pack))
+        items.append(("host", "emb", lambda: dist.all_to_all_single(
+            self.g_recv[:n_send], self.g_send[:n_recv], self.send_splits, self.recv_splits, group=self.pg)))
         if self.Tl:
-            self.ws_sparse = ops.embbag_backward_update(grad=self.g_recv, grad_ld=self.Tl * D,
-                                                        **self._emb_kwargs(indices, offsets), **kw)
+            items.append(("ops", "emb", update(self._emb_kwargs, self.g_recv, self.Tl * D)))
         if self.Trw:
             c0 = self.emb_col0 + self.plan.n_table_wise * D
-            ops.copy_2d_(self.rw_local, self.dfeat[:, c0:c0 + self.Trw * D])
-            dist.all_gather_into_tensor(self.rw_part, self.rw_local, group=self.pg)
-            kw["workspace"] = self.ws_sparse
-            self.ws_sparse = ops.embbag_backward_update(grad=self.rw_part, grad_ld=self.Trw * D,
-                                                        **self._rw_kwargs(indices, offsets), **kw)
+            items.append(("ops", "emb", lambda: ops.copy_2d_(self.rw_local, self.dfeat[:, c0:c0 + self.Trw * D])))
+            items.append(("host", "emb", lambda: dist.all_gather_into_tensor(self.rw_part, self.rw_local, group=self.pg)))
+            items.append(("ops", "emb", update(self._rw_kwargs, self.rw_part, self.Trw * D)))
+        return items
+
+    def _forward_items(self, indices, offsets):
+        """Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
+        cfg = self.cfg
+        items = [("wait", "emb", "main")]        # earlier readers of feat and the input copies are done
+        items += self._emb_forward_items(indices, offsets)
+        items.append(("ops", "main", lambda: self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)))
+        items.append(("wait", "main", "emb"))
+
+        def top():
+            if cfg.interaction == "dot":
+                ops.interact_dot_forward(self.feat.view(self.B, cfg.num_features, cfg.dim), out=self.inter,
+                                         out_ld=self.inter_ld)
+            self.top.forward(self.inter[:, :cfg.top_in], self.top_acts)
+        items.append(("ops", "main", top))
+        return items
+
+    def _train_items(self, indices, offsets):
+        """One iteration of the reference's loop body (src/dlrmtest.cpp:505-535)."""
+        cfg = self.cfg
+        items = self._forward_items(indices, offsets)
+
+        def loss_and_top_backward():
+            if cfg.loss == "bce":
+                ops.loss_bce_logits(self.pred.view(-1), self.labels, loss=self.loss, dlogit=self.dpred.view(-1),
+                                    mean_over=self.Bg)
+            else:
+                ops.loss_mse(self.pred.view(-1), self.labels, relu_mask_pred=cfg.final_relu, loss=self.loss,
+                             dpred=self.dpred.view(-1), mean_over=self.Bg)
+            if cfg.interaction == "dot":
+                self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
+                                                  self.ws_dense, dx_first=self.dinter[:, :cfg.top_in])
+                ops.interact_dot_backward(self.feat.view(self.B, cfg.num_features, cfg.dim),
+                                          self.dinter[:, :cfg.top_in], relu_mask_feature0=True,
+                                          out=self.dfeat.view(self.B, cfg.num_features, cfg.dim))
+            else:
+                self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
+                                                  self.ws_dense, dx_first=None)
+                nb = cfg.bottom[-1]
+                dz0 = self.top_dz[0] if self.top.n_layers > 1 else self.dpred
+                # bottom part of the concatenation is a ReLU output, the pooled part is not
+                ops.linear_backward_data(dz0, self.top.W[0][:, :nb], relu_mask=self.feat[:, :nb], out=self.dfeat[:, :nb])
+                ops.linear_backward_data(dz0, self.top.W[0][:, nb:], out=self.dfeat[:, nb:cfg.top_in])
+        items.append(("ops", "main", loss_and_top_backward))
+        # sparse rows (exchange + fused update) beside the bottom MLP's backward
+        items.append(("wait", "emb", "main"))     # dfeat is complete
+        items += self._emb_backward_items(indices, offsets)
+
+        def bottom_backward():
+            self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
+                                                 self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
+        items.append(("ops", "main", bottom_backward))
+        items.append(("wait", "main", "emb"))     # rows are updated before anyone reuses dfeat
+        if self.world > 1:
+            import torch.distributed as dist
+            items.append(("host", "main", lambda: dist.all_reduce(self.grads, group=self.pg)))
+        items.append(("ops", "main", lambda: ops.sgd_step_(self.params, self.grads, cfg.lr)))
+        return items
+
+    def _streams(self):
+        main = torch.cuda.current_stream() if self.dev.type == "cuda" else None
+        return {"main": main, "emb": self.side if self.side is not None else main}
+
+    def _run_items(self, items, plan=None):
+        """Executes a schedule.  Without a plan the "ops" items launch their operators now; with one,
+        every "ops" item is a pair (first, last) of recorded entries replayed by one C call."""
+        st = self._streams()
+        for kind, a, b in items:
+            if kind == "wait":
+                if st[a] is not None and st[a] != st[b]:
+                    st[a].wait_stream(st[b])
+            elif kind == "ops" and plan is not None:
+                plan.run(b[0], b[1], st[a])
+            elif st[a] is None or st[a] == st["main"]:
+                b()
+            else:
+                with torch.cuda.stream(st[a]):
+                    b()
+
+    def _record(self, items, indices, offsets):
+        """Traces the "ops" items of a schedule into a dlrm_plan (nothing is launched)."""
+        from .plan import StepRecorder
+        rec = StepRecorder(indices, offsets)
+        out = []
+        with rec:
+            for kind, a, b in items:
+                if kind == "ops":
+                    first = rec.size
+                    b()
+                    out.append((kind, a, (first, rec.size)))
+                else:
+                    out.append((kind, a, b))
+        return rec.plan, out
 
     # ------------------------------------------------------------------ step
 
@@ -437,22 +557,8 @@ class DLRM:
         self.labels.copy_(labels.reshape(-1))
 
     def forward(self, indices, offsets):
-        """Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
-        cfg = self.cfg
-        if self.side is None:
-            self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
-            self.embedding_forward(indices, offsets)
-        else:
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)          # earlier readers of feat and the input copies are done
-            with torch.cuda.stream(self.side):
-                self.embedding_forward(indices, offsets)
-            self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)
-            main.wait_stream(self.side)
-        if cfg.interaction == "dot":
-            ops.interact_dot_forward(self.feat.view(self.B, cfg.num_features, cfg.dim), out=self.inter,
-                                     out_ld=self.inter_ld)
-        self.top.forward(self.inter[:, :cfg.top_in], self.top_acts)
+        """Inference: Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
+        self._run_items(self._forward_items(indices, offsets))
         return self.pred
 
     def train_step(self, indices, offsets, next_indices=None, table_pos=None, next_table_pos=None):
@@ -461,8 +567,9 @@ class DLRM:
         row update.  Returns the device scalar holding this rank's share of the
         global-mean loss.  Cached tables: ids are looked up first (or were prefetched by the
         previous call through next_indices) and the cache is reclaimed at the end
-        (reclaim_emb_cache, src/dlrmtest.cpp:397-412, :494)."""
-        cfg = self.cfg
+        (reclaim_emb_cache, src/dlrmtest.cpp:397-412, :494).
+        With `replay` the step's operators are recorded into a dlrm_plan on the first call and
+        replayed afterwards (same kernels, same order, one C call per stretch between collectives)."""
         pipelined = False
         if self.cache is not None:
             if self._rows is not None and self._rows[0] is indices:
@@ -480,43 +587,17 @@ class DLRM:
             self._rows = None
             pipelined = next_indices is not None
             indices = rows
-        self.forward(indices, offsets)
-        if cfg.loss == "bce":
-            ops.loss_bce_logits(self.pred.view(-1), self.labels, loss=self.loss, dlogit=self.dpred.view(-1),
-                                mean_over=self.Bg)
+        if not self.replay:
+            self._run_items(self._train_items(indices, offsets))
         else:
-            ops.loss_mse(self.pred.view(-1), self.labels, relu_mask_pred=cfg.final_relu, loss=self.loss,
-                         dpred=self.dpred.view(-1), mean_over=self.Bg)
-        # top MLP
-        if cfg.interaction == "dot":
-            self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
-                                              self.ws_dense, dx_first=self.dinter[:, :cfg.top_in])
-            ops.interact_dot_backward(self.feat.view(self.B, cfg.num_features, cfg.dim), self.dinter[:, :cfg.top_in],
-                                      relu_mask_feature0=True, out=self.dfeat.view(self.B, cfg.num_features, cfg.dim))
-        else:
-            self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
-                                              self.ws_dense, dx_first=None)
-            nb = cfg.bottom[-1]
-            dz0 = self.top_dz[0] if self.top.n_layers > 1 else self.dpred
-            # bottom part of the concatenation is a ReLU output, the pooled part is not
-            ops.linear_backward_data(dz0, self.top.W[0][:, :nb], relu_mask=self.feat[:, :nb], out=self.dfeat[:, :nb])
-            ops.linear_backward_data(dz0, self.top.W[0][:, nb:], out=self.dfeat[:, nb:cfg.top_in])
-        # sparse rows (exchange + fused update) beside the bottom MLP's backward
-        if self.side is None:
-            self.embedding_backward_update(indices, offsets)
-        else:
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)          # dfeat is complete
-            with torch.cuda.stream(self.side):
-                self.embedding_backward_update(indices, offsets)
-        self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
-                                             self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)   # rows are updated before anyone reuses dfeat
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, group=self.pg)
-        ops.sgd_step_(self.params, self.grads, cfg.lr)
+            key = (indices.dtype, indices.numel(), offsets.numel())
+            if self._plan is None or self._plan_key != key:
+                self._plan, self._plan_items = self._record(self._train_items(indices, offsets), indices, offsets)
+                self._plan_key = key
+                if self.plan_timing_runs:
+                    self._plan.enable_timing(self.plan_timing_runs)
+            self._plan.set_batch(indices, offsets)
+            self._run_items(self._plan_items, self._plan)
         if self.cache is not None:
             if pipelined:
                 self._pipeline_next(next_indices, next_table_pos)

@@ -15,6 +15,33 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# While a StepRecorder is installed (dlrm_amd.plan), the operators below do everything except launch:
+# their C-ABI call is handed to the recorder, which appends it to a dlrm_plan.
+_recorder = None
+
+
+def _emit(name, *args):
+    """Launch `dlrm_<name>(*args, stream)` now, or record it."""
+    if _recorder is None:
+        args = [C.byref(a) if isinstance(a, C.Structure) else a for a in args]
+        check(getattr(_capi.lib(), "dlrm_" + name)(*args, _stream()))
+    else:
+        _recorder.add(name, args)
+
+
+def _op(fn):
+    """Marks a public operator: a recorder learns which operator (and with which arguments) the
+    entries recorded next belong to."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        if _recorder is not None:
+            _recorder.note(fn.__name__, a, kw)
+        return fn(*a, **kw)
+    return wrapped
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -82,6 +109,7 @@ def make_embbag_desc(weight, indices, offsets, batch, num_tables=1, table_row_of
     return d
 
 
+@_op
 def embbag_forward(weight, indices, offsets, batch, num_tables=1, table_row_offsets=None,
                    pooling=_capi.POOL_SUM, include_last_offset=False, out=None, out_ld=None,
                    error_flag=None, shard_row_begin=None):
@@ -96,7 +124,7 @@ def embbag_forward(weight, indices, offsets, batch, num_tables=1, table_row_offs
     else:
         _require_cuda(out)
         assert out.dtype == torch.float32 and out_ld is not None
-    check(_capi.lib().dlrm_embbag_forward(C.byref(d), _ptr(out), C.c_int64(out_ld), _stream()))
+    _emit("embbag_forward", d, _ptr(out), C.c_int64(out_ld))
     return out
 
 
@@ -106,6 +134,7 @@ def embbag_backward_workspace_bytes(desc):
     return int(n.value)
 
 
+@_op
 def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, table_row_offsets=None,
                            pooling=_capi.POOL_SUM, include_last_offset=False, optimizer=_capi.OPT_SGD,
                            dup_mode=_capi.DUP_ACCUMULATE, lr=0.01, eps=1e-8, opt_state=None, grad_ld=None,
@@ -126,8 +155,8 @@ def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, 
     o = SparseOpt()
     o.optimizer, o.dup_mode, o.lr, o.eps = optimizer, dup_mode, lr, eps
     o.d_opt_state = 0 if opt_state is None else opt_state.data_ptr()
-    check(_capi.lib().dlrm_embbag_backward_update(C.byref(d), _ptr(grad), C.c_int64(grad_ld), C.byref(o),
-                                                  _ptr(workspace), C.c_size_t(workspace.numel()), _stream()))
+    _emit("embbag_backward_update", d, _ptr(grad), C.c_int64(grad_ld), o, _ptr(workspace),
+          C.c_size_t(workspace.numel()))
     return workspace
 
 
@@ -139,6 +168,7 @@ def _ld(t):
     return t.stride(0)
 
 
+@_op
 def linear_forward(x, w, bias, relu, out=None):
     """y = act(x W^T + b).  x [M,K] and w [N,K] may be column slices of wider
     (padded) buffers: the row stride is passed as the leading dimension."""
@@ -155,10 +185,11 @@ def linear_forward(x, w, bias, relu, out=None):
     d.d_bias = 0 if bias is None else bias.data_ptr()
     d.d_y, d.y_ld = out.data_ptr(), _ld(out)
     d.act = _capi.ACT_RELU if relu else _capi.ACT_NONE
-    check(_capi.lib().dlrm_linear_forward(C.byref(d), _stream()))
+    _emit("linear_forward", d)
     return out
 
 
+@_op
 def linear_backward_data(dz, w, relu_mask=None, out=None):
     """dx = dz W, optionally masked with (relu_mask > 0)."""
     _require_cuda(dz, w, relu_mask, out)
@@ -173,7 +204,7 @@ def linear_backward_data(dz, w, relu_mask=None, out=None):
     d.d_dx, d.dx_ld = out.data_ptr(), _ld(out)
     if relu_mask is not None:
         d.d_relu_mask, d.relu_mask_ld = relu_mask.data_ptr(), _ld(relu_mask)
-    check(_capi.lib().dlrm_linear_backward_data(C.byref(d), _stream()))
+    _emit("linear_backward_data", d)
     return out
 
 
@@ -183,6 +214,7 @@ def linear_backward_weight_workspace_bytes(M, N, K):
     return int(n.value)
 
 
+@_op
 def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True):
     """dW = dz^T x [N,K], db = column sums of dz."""
     _require_cuda(dz, x, dw, db, workspace)
@@ -201,21 +233,22 @@ def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True
     d.d_x, d.x_ld = x.data_ptr(), _ld(x)
     d.d_dw, d.dw_ld = dw.data_ptr(), _ld(dw)
     d.d_db = 0 if db is None else db.data_ptr()
-    check(_capi.lib().dlrm_linear_backward_weight(C.byref(d), _ptr(workspace), C.c_size_t(workspace.numel()),
-                                                  _stream()))
+    _emit("linear_backward_weight", d, _ptr(workspace), C.c_size_t(workspace.numel()))
     return dw, db, workspace
 
 
+@_op
 def sgd_step_(w, g, lr):
     _require_cuda(w, g)
     assert w.is_contiguous() and g.is_contiguous() and w.numel() == g.numel()
-    check(_capi.lib().dlrm_sgd_step(_ptr(w), _ptr(g), C.c_int64(w.numel()), C.c_float(lr), _stream()))
+    _emit("sgd_step", _ptr(w), _ptr(g), C.c_int64(w.numel()), C.c_float(lr))
     return w
 
 
 # ------------------------------------------------- interaction and losses
 
 
+@_op
 def interact_dot_forward(x, out=None, out_ld=None):
     """x [B,F,D] -> [B, D + F(F-1)/2] (row stride out_ld, tail zero-filled)."""
     _require_cuda(x, out)
@@ -225,48 +258,52 @@ def interact_dot_forward(x, out=None, out_ld=None):
     if out is None:
         out_ld = n_out if out_ld is None else out_ld
         out = torch.empty((B, out_ld), dtype=torch.float32, device=x.device)
-    check(_capi.lib().dlrm_interact_dot_forward(_ptr(x), C.c_int64(B), F, D, _ptr(out), C.c_int64(out_ld), _stream()))
+    _emit("interact_dot_forward", _ptr(x), C.c_int64(B), C.c_int32(F), C.c_int32(D), _ptr(out), C.c_int64(out_ld))
     return out
 
 
+@_op
 def interact_dot_backward(x, dout, relu_mask_feature0=False, out=None):
     _require_cuda(x, dout, out)
     B, F, D = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(_capi.lib().dlrm_interact_dot_backward(_ptr(x), _ptr(dout), C.c_int64(_ld(dout)), C.c_int64(B), F, D,
-                                                 _ptr(out), int(relu_mask_feature0), _stream()))
+    _emit("interact_dot_backward", _ptr(x), _ptr(dout), C.c_int64(_ld(dout)), C.c_int64(B), C.c_int32(F), C.c_int32(D),
+          _ptr(out), C.c_int32(int(relu_mask_feature0)))
     return out
 
 
+@_op
 def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None):
     _require_cuda(pred, target)
     n = pred.numel()
     assert pred.is_contiguous() and target.is_contiguous() and target.numel() == n
     loss = torch.empty(1, dtype=torch.float32, device=pred.device) if loss is None else loss
     dpred = torch.empty_like(pred) if dpred is None else dpred
-    check(_capi.lib().dlrm_loss_mse(_ptr(pred), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss), _ptr(dpred),
-                                    int(relu_mask_pred), _stream()))
+    _emit("loss_mse", _ptr(pred), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss), _ptr(dpred),
+          C.c_int32(int(relu_mask_pred)))
     return loss, dpred
 
 
+@_op
 def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None):
     _require_cuda(logit, target)
     n = logit.numel()
     assert logit.is_contiguous() and target.is_contiguous() and target.numel() == n
     loss = torch.empty(1, dtype=torch.float32, device=logit.device) if loss is None else loss
     dlogit = torch.empty_like(logit) if dlogit is None else dlogit
-    check(_capi.lib().dlrm_loss_bce_logits(_ptr(logit), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss),
-                                           _ptr(dlogit), _stream()))
+    _emit("loss_bce_logits", _ptr(logit), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss),
+          _ptr(dlogit))
     return loss, dlogit
 
 
+@_op
 def copy_2d_(dst, src):
     """dst[:, :] = src[:, :] for two row-major 2-D float32 views (any row strides)."""
     _require_cuda(dst, src)
     assert dst.shape == src.shape and dst.dtype == torch.float32 and src.dtype == torch.float32
-    check(_capi.lib().dlrm_copy_2d(_ptr(dst), C.c_int64(_ld(dst)), _ptr(src), C.c_int64(_ld(src)),
-                                   C.c_int64(dst.shape[0]), C.c_int64(dst.shape[1]), _stream()))
+    _emit("copy_2d", _ptr(dst), C.c_int64(_ld(dst)), _ptr(src), C.c_int64(_ld(src)), C.c_int64(dst.shape[0]),
+          C.c_int64(dst.shape[1]))
     return dst
 
 

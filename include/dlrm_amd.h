@@ -51,7 +51,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1001
+#define DLRM_ABI_VERSION 1002
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -310,6 +310,54 @@ typedef struct dlrm_cache_state_t {
     int64_t last_lookup_pages_read; /* pages the last lookup read from the store */
     int64_t total_pages, num_slots;
 } dlrm_cache_state_t;
+
+/* ---- recorded step ------------------------------------------------------------------------
+ *
+ * No counterpart in the reference (it re-creates modules and an autograd graph for every batch,
+ * src/dlrmtest.cpp:473-545).  The launches of a step are described once -- dlrm_plan_add_* take the
+ * same arguments as the calls above and copy the descriptors -- and replayed per batch:
+ * dlrm_plan_set_batch patches the index / offset pointers of every EmbeddingBag entry, dlrm_plan_run
+ * replays entries [first, last) on a stream (a sharded step replays one range per stretch between
+ * two collectives).  Every add returns the entry's number (>= 0), or -1 with the message set.  EmbeddingBag entries take the position of their first offset
+ * inside the batch's offset array instead of pointers (indices are addressed absolutely by the
+ * offsets).  Optional per-entry timing with events on the replay stream: dlrm_plan_enable_timing
+ * (max_runs replays of an entry between two collects; 0 switches it off), dlrm_plan_collect_timing
+ * waits for the recorded events and returns milliseconds summed per entry and the replay counts.
+ */
+typedef struct dlrm_plan dlrm_plan;
+enum {
+    DLRM_OP_EMBBAG_FORWARD = 0, DLRM_OP_EMBBAG_BACKWARD_UPDATE = 1, DLRM_OP_LINEAR_FORWARD = 2,
+    DLRM_OP_LINEAR_BACKWARD_DATA = 3, DLRM_OP_LINEAR_BACKWARD_WEIGHT = 4, DLRM_OP_SGD_STEP = 5,
+    DLRM_OP_INTERACT_DOT_FORWARD = 6, DLRM_OP_INTERACT_DOT_BACKWARD = 7, DLRM_OP_LOSS = 8, DLRM_OP_COPY_2D = 9
+};
+int dlrm_plan_create(dlrm_plan **out);
+int dlrm_plan_destroy(dlrm_plan *p);
+int dlrm_plan_size(const dlrm_plan *p);
+int dlrm_plan_op(const dlrm_plan *p, int entry);
+int dlrm_plan_set_batch(dlrm_plan *p, const void *d_indices, const void *d_offsets, int64_t n_indices);
+int dlrm_plan_add_embbag_forward(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first, float *d_out,
+                                 int64_t out_ld);
+int dlrm_plan_add_embbag_backward_update(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first,
+                                         const float *d_grad, int64_t grad_ld, const dlrm_sparse_opt *opt,
+                                         void *d_workspace, size_t workspace_bytes);
+int dlrm_plan_add_linear_forward(dlrm_plan *p, const dlrm_linear *l);
+int dlrm_plan_add_linear_backward_data(dlrm_plan *p, const dlrm_linear_bwd *l);
+int dlrm_plan_add_linear_backward_weight(dlrm_plan *p, const dlrm_linear_bwd *l, void *d_workspace,
+                                         size_t workspace_bytes);
+int dlrm_plan_add_sgd_step(dlrm_plan *p, float *d_w, const float *d_g, int64_t n, float lr);
+int dlrm_plan_add_interact_dot_forward(dlrm_plan *p, const float *d_x, int64_t B, int32_t F, int32_t D, float *d_out,
+                                       int64_t out_ld);
+int dlrm_plan_add_interact_dot_backward(dlrm_plan *p, const float *d_x, const float *d_dout, int64_t dout_ld,
+                                        int64_t B, int32_t F, int32_t D, float *d_dx, int32_t relu_mask_feature0);
+int dlrm_plan_add_loss_mse(dlrm_plan *p, const float *d_pred, const float *d_target, int64_t n, int64_t mean_over,
+                           float *d_loss, float *d_dpred, int32_t relu_mask_pred);
+int dlrm_plan_add_loss_bce_logits(dlrm_plan *p, const float *d_logit, const float *d_target, int64_t n,
+                                  int64_t mean_over, float *d_loss, float *d_dlogit);
+int dlrm_plan_add_copy_2d(dlrm_plan *p, float *d_dst, int64_t dst_ld, const float *d_src, int64_t src_ld, int64_t rows,
+                          int64_t cols);
+int dlrm_plan_enable_timing(dlrm_plan *p, int32_t max_runs);
+int dlrm_plan_run(dlrm_plan *p, int32_t first, int32_t last, dlrm_stream_t stream);
+int dlrm_plan_collect_timing(dlrm_plan *p, double *h_ms_sum, int32_t *h_runs);
 
 /* Pinned, device-mapped host memory for backing stores (hipHostMalloc). */
 int dlrm_host_alloc(void **h_ptr, size_t bytes);

@@ -27,7 +27,7 @@ def test_cached_training_matches_oracle(oracle, rows_per_page, prefetch, kind):
     # capacities small enough that pages are evicted within the 8 steps, large enough that no page of
     # the running (or prefetched) batch is among the victims
     m = DLRM(cfg, B, seed=5, cache_fraction=0.5 if kind == "dot" else (0.1 if rows_per_page == 1 else 0.35),
-             cache_rows_per_page=rows_per_page)
+             cache_rows_per_page=rows_per_page, replay=prefetch)   # the pipelined runs also replay a recorded step
     if kind == "cat":
         for b in m.bottom.b + m.top.b:
             b.abs_()

@@ -38,11 +38,12 @@ def get_state(m):
 @pytest.mark.parametrize("name", ["mlperf_like", "kaggle_like", "rmc1_like", "adagrad_bf16rows_off"])
 @pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("overlap", [False, True])      # True: embedding side on a second HIP stream
-def test_train_step_matches_oracle(oracle, name, ragged, overlap):
+@pytest.mark.parametrize("replay", [False, True])       # True: the step is recorded once and replayed (dlrm_plan)
+def test_train_step_matches_oracle(oracle, name, ragged, overlap, replay):
     from dlrm_amd.model import DLRM
     cfg = small_cfgs()[name]
     B = 37
-    m = DLRM(cfg, B, seed=3, overlap=overlap)
+    m = DLRM(cfg, B, seed=3, overlap=overlap, replay=replay)
     assert (m.side is not None) == overlap
     if name == "rmc1_like":
         # positive biases keep the all-ReLU reference model alive
@@ -51,7 +52,7 @@ def test_train_step_matches_oracle(oracle, name, ragged, overlap):
     tables, Ws, bs = get_state(m)
     state = None if m.opt_state is None else m.opt_state.cpu().numpy().copy()
     rng = np.random.default_rng(17)
-    for step in range(2):
+    for step in range(int(__import__('os').environ.get('NSTEPS', '3'))):
         dense, idx, off, labels = make_batch(rng, cfg, B, ragged)
         m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
         loss = m.train_step(torch.from_numpy(idx).cuda(), torch.from_numpy(off).cuda())
