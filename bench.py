@@ -150,9 +150,13 @@ def main():
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
     ap.add_argument("--eager", action="store_true",
                     help="launch every operator from Python instead of replaying the recorded step (dlrm_plan)")
+    ap.add_argument("--replay", action="store_true",
+                    help="N>1: replay the recorded step too (default there is eager; one GPU replays by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not args.replay:
+        args.eager = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
