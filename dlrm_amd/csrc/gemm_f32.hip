@@ -747,7 +747,7 @@ static int vec_ok(const void *p, int64_t ld) { return aligned16(p) && ld % 4 == 
 
 static int choose_splits(int M_red, int tiles) {
     // enough workgroups for 256 CUs x 2, each split at least 8 reduction steps deep
-    int want = (int)ceil_div(1024, tiles);
+    int want = (int)ceil_div(512, tiles);
     int max_by_depth = M_red / (BK * 8);
     if (max_by_depth < 1) max_by_depth = 1;
     int s = want < max_by_depth ? want : max_by_depth;

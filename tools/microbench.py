@@ -35,17 +35,18 @@ def pad4(n):
 
 
 def gemm(shapes=None):
-    M = 65536
+    M = int(os.environ.get("GEMM_M", "65536"))
     shapes = shapes or [(1024, 1024), (1024, 479), (512, 1024), (256, 512), (512, 13), (128, 256), (1, 256)]
+    pad = (lambda n: n if n <= 128 else (n + 127) // 128 * 128) if os.environ.get("GEMM_PADK") else pad4
     out = []
     for N, K in shapes:
-        x = torch.randn(M, pad4(K), device="cuda")[:, :K]
-        w = torch.randn(N, pad4(K), device="cuda")[:, :K]
+        x = torch.randn(M, pad(pad4(K)), device="cuda")[:, :K]
+        w = torch.randn(N, pad(pad4(K)), device="cuda")[:, :K]
         b = torch.randn(N, device="cuda")
-        y = torch.empty(M, pad4(N), device="cuda")[:, :N]
-        dz = torch.randn(M, pad4(N), device="cuda")[:, :N]
-        dx = torch.empty(M, pad4(K), device="cuda")[:, :K]
-        dw = torch.empty(N, pad4(K), device="cuda")[:, :K]
+        y = torch.empty(M, pad(pad4(N)), device="cuda")[:, :N]
+        dz = torch.randn(M, pad(pad4(N)), device="cuda")[:, :N]
+        dx = torch.empty(M, pad(pad4(K)), device="cuda")[:, :K]
+        dw = torch.empty(N, pad(pad4(K)), device="cuda")[:, :K]
         db = torch.empty(N, device="cuda")
         ws = torch.empty(ops.linear_backward_weight_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
         fl = 2.0 * M * N * K
