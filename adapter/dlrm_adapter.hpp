@@ -167,6 +167,13 @@ public:
         return st.error_flags;
     }
 
+    // Cumulative per-table counters {read, write, hit, miss, evicted, resident} as of the last
+    // refresh: what the reference's CSV cannot say (its rows only carry pages read / written).
+    const std::vector<int64_t> &counters() {
+        refresh();
+        return last_;
+    }
+
     // public state the reference driver reads (include/data.h:288-291)
     int cache_size;
     int page_count;

@@ -8,6 +8,8 @@
 //   --tables T --dim D --rows R --lookups L --dense F --epochs E
 //   --input FILE     dataset + FC weights (see read_input); default: generated in-process
 //   --csv FILE       page traffic log, reference schema 'Time';'Channel';'PU';'Read';'Write' (:448)
+//   --trace FILE     per batch and table: lookups that hit / missed, pages read / written / evicted / resident
+//                    ('Time';'Epoch';'Batch';'Table';'Hit';'Miss';'Read';'Write';'Evicted';'Resident'; deltas per batch)
 //   --canonical      train every table (duplicates accumulate) and the MLP instead of the loop as shipped
 //   --dump-table0 F  write table 0 (float32 [rows][dim]) after training, for parity checks
 //
@@ -92,7 +94,7 @@ int main(int argc, char *argv[]) {
     try {
         Model m;
         int data_size = 800, batch_size = 60, c = 6;   // src/dlrmtest.cpp:45-47
-        std::string input, csv_path, dump0;
+        std::string input, csv_path, dump0, trace_path;
         bool canonical = false;
         std::vector<std::string> pos;
         for (int i = 1; i < argc; i++) {
@@ -106,6 +108,7 @@ int main(int argc, char *argv[]) {
             else if (a == "--epochs") m.epochs = std::stoi(next());
             else if (a == "--input") input = next();
             else if (a == "--csv") csv_path = next();
+            else if (a == "--trace") trace_path = next();
             else if (a == "--canonical") canonical = true;
             else if (a == "--dump-table0") dump0 = next();
             else pos.push_back(a);
@@ -118,6 +121,13 @@ int main(int argc, char *argv[]) {
                                                   std::to_string(data_size) + ".csv" : csv_path;
         std::ofstream myfile(name);
         myfile << "'Time';'Channel';'PU';'Read';'Write'" << std::endl;   // :448
+
+        std::ofstream trace;
+        std::vector<int64_t> trace_prev;
+        if (!trace_path.empty()) {
+            trace.open(trace_path);
+            trace << "'Time';'Epoch';'Batch';'Table';'Hit';'Miss';'Read';'Write';'Evicted';'Resident'" << std::endl;
+        }
 
         Input in;
         if (input.empty()) make_input(m, data_size, in); else read_input(input, m, data_size, in);
@@ -148,6 +158,18 @@ int main(int argc, char *argv[]) {
                 emb embedding(xb, B, m.dense, m.L, emb_cache, &myfile, now());
                 reclaim_emb_cache(emb_cache, &myfile, now());
                 if (b + 1 == c && epoch == 1) emb_cache.cache_size = emb_cache.page_count;   // :496-498
+                if (trace.is_open()) {
+                    const std::vector<int64_t> cur = emb_cache.counters();
+                    if (trace_prev.empty()) trace_prev.assign(cur.size(), 0);
+                    const double tnow = now();
+                    for (int t = 0; t < m.T; t++) {
+                        trace << tnow << ";" << epoch << ";" << b << ";" << t;
+                        static const int order[5] = {2, 3, 0, 1, 4};   // hit, miss, read, write, evicted
+                        for (int k : order) trace << ";" << cur[t * 6 + k] - trace_prev[t * 6 + k];
+                        trace << ";" << cur[t * 6 + 5] << "\n";
+                    }
+                    trace_prev = cur;
+                }
 
                 std::vector<float> xd((size_t)B * m.dense);
                 for (int i = 0; i < B; i++) std::memcpy(&xd[(size_t)i * m.dense], xb + (size_t)i * row, sizeof(float) * m.dense);

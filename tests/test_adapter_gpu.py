@@ -101,8 +101,22 @@ def test_driver_rmc1_matches_reference_csv(tmp_path):
     b = [np.abs(rng.standard_normal(n)).astype(np.float32) * 0.1 for n in (128, 32, 32, 1)]
     inp, csv = tmp_path / "in.bin", tmp_path / "out.csv"
     write_input(inp, np.concatenate([x, ids.astype(np.float32)], axis=1), y.reshape(-1), W, b, T, D, rows, L, 256)
-    lines = run_driver([N, B, c, "--input", inp, "--csv", csv], tmp_path)
+    trace = tmp_path / "out.trace.csv"
+    lines = run_driver([N, B, c, "--input", inp, "--csv", csv, "--trace", trace], tmp_path)
     got = [{"read": sum(r), "write": sum(w)} for r, w in parse_csv(csv, T)]
     assert got == cfg["batches"]
+    # the log tooling sees the same totals in both files, and every lookup is a hit or a miss
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "cache_trace", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cache_trace.py"))
+    ct = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ct)
+    pages, tr = ct.read_pages(str(csv), T), ct.read_trace(str(trace))
+    assert [{"read": p["read"], "write": p["write"]} for p in pages] == cfg["batches"]
+    assert [t["read"] for t in tr] == [p["read"] for p in pages]
+    assert [t["write"] for t in tr] == [p["write"] for p in pages]
+    sizes = [min(B, N - s) for s in range(0, N, B)]
+    assert [t["hit"] + t["miss"] for t in tr] == [T * L * n for _ in range(len(tr) // len(sizes)) for n in sizes]
     assert lines[-1]["error_flags"] == 0
     assert all(np.isfinite(l["loss"]) for l in lines if "loss" in l)
