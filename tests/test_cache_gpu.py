@@ -123,3 +123,30 @@ def test_rmc1_reference_run_matches_reference_csv():
     assert cache.state().error_flags == 0
     assert trace == cfg["batches"]
     cache.close()
+
+
+def test_store_image_roundtrip_through_the_cache(tmp_path):
+    """An image in the reference's on-disk layout is loaded into the pinned store, rows are updated inside
+    the HBM cache, and the saved image holds exactly the updated rows."""
+    from dlrm_amd import ops, store_file
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(3)
+    rows, D, T = [300, 77], 32, 2
+    tables = [rng.random((r, D), dtype=np.float32) for r in rows]
+    src, dst = tmp_path / "in.img", tmp_path / "out.img"
+    store_file.write_store(src, tables)
+    c = EmbeddingCache(rows, D, cache_size=8, num_slots=64)
+    store_file.load_into(c, src)
+    ids = torch.tensor([5, 200, 299, 0, 76, 5], dtype=torch.int32, device="cuda")     # 3 of table 0, 3 of table 1
+    r = c.get_emb_vectors(ids, [0, 3, 6])
+    got = c.pool[r.long()].cpu().numpy()
+    want = np.stack([tables[0][5], tables[0][200], tables[0][299], tables[1][0], tables[1][76], tables[1][5]])
+    assert np.array_equal(got, want)
+    c.pool[r.long()[:3]] += 1.0                   # rows 5, 200, 299 of table 0 change inside the cache
+    torch.cuda.synchronize()
+    assert store_file.save_from(c, dst) == store_file.image_bytes(rows, D)
+    back = store_file.read_store(dst, rows, D, copy=True)
+    exp0 = tables[0].copy()
+    exp0[[5, 200, 299]] += 1.0
+    assert np.array_equal(back[0], exp0) and np.array_equal(back[1], tables[1])
+    c.close()
