@@ -51,7 +51,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1002
+#define DLRM_ABI_VERSION 1003
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -310,6 +310,19 @@ typedef struct dlrm_cache_state_t {
     int64_t last_lookup_pages_read; /* pages the last lookup read from the store */
     int64_t total_pages, num_slots;
 } dlrm_cache_state_t;
+
+/* ---- input decoding ------------------------------------------------------------------------
+ *
+ * Criteo click logs in the MLPerf-DLRM binary layout (per sample: int32 label, n_dense int32 counters,
+ * n_sparse int32 hashed category ids), decoded on the device into the step's inputs: dense features
+ * log(max(x,0)+1) [n, dense_ld] float32, labels float32, ids table-major (bag g = t*n + b, one id per
+ * bag, taken modulo d_table_rows[t] when given) and offsets 0..n_sparse*n (n_sparse*n + 1 entries).
+ * Replaces the float-encoded feature tensor of MyDataset (src/dlrmtest.cpp:299-334), which carries ids
+ * as floats and is split again by create_emb (:53-63).
+ */
+int dlrm_criteo_decode(const int32_t *d_records, int64_t n_samples, int32_t n_dense, int32_t n_sparse,
+                       const int64_t *d_table_rows, float *d_dense, int64_t dense_ld, float *d_labels,
+                       void *d_indices, void *d_offsets, int32_t idx_dtype, dlrm_stream_t stream);
 
 /* ---- recorded step ------------------------------------------------------------------------
  *
