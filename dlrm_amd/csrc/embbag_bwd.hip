@@ -576,27 +576,80 @@ static int dispatch_update(const BwdParams &p, const KEY *keys, const int32_t *v
     return set_error(DLRM_ERR_INVALID, "dim=%d is too wide for the sparse update (max 1024)", p.D);
 }
 
+// phases of the backward: 1 = expand + sort (needs the ids only), 2 = reduce + update (needs the
+// gradients and a workspace that phase 1 filled for the same ids), 3 = both
 template <typename IDX, typename KEY>
 static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_bytes, bool vec16, int lanes,
-                        hipStream_t s) {
+                        int phases, hipStream_t s) {
     WsLayout<KEY> L;
     const int bits = key_bits(e->total_rows);
     if (int rc = ws_layout<KEY>(e->n_indices, bits, e->dim, ws, &L)) return rc;
     DLRM_REQUIRE(ws_bytes >= L.total, "workspace too small: %zu < %zu bytes", ws_bytes, L.total);
 
-    const double avg_len = (double)e->n_indices / (double)p.n_bags;
-    int lpb = 1;
-    while (lpb < 64 && lpb * 2 <= avg_len) lpb <<= 1;
-    const int64_t blocks = ceil_div(p.n_bags * lpb, kBwdThreads);
-    hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks), dim3(kBwdThreads), 0, s, p, lpb,
-                       L.keys_in, L.vals_in);
-    DLRM_LAUNCH_CHECK();
-    size_t tmp = L.sort_tmp_bytes;
-    DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
-                                       (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
+    if (phases & 1) {
+        const double avg_len = (double)e->n_indices / (double)p.n_bags;
+        int lpb = 1;
+        while (lpb < 64 && lpb * 2 <= avg_len) lpb <<= 1;
+        const int64_t blocks = ceil_div(p.n_bags * lpb, kBwdThreads);
+        hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks), dim3(kBwdThreads), 0, s, p, lpb,
+                           L.keys_in, L.vals_in);
+        DLRM_LAUNCH_CHECK();
+        size_t tmp = L.sort_tmp_bytes;
+        DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
+                                           (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
+    }
+    if (!(phases & 2)) return DLRM_OK;
     if (e->row_dtype == DLRM_BF16)
         return dispatch_update<IDX, KEY, uint16_t>(p, L.keys_out, L.vals_out, L.partial, pad_dim(e->dim), vec16, lanes, s);
     return dispatch_update<IDX, KEY, float>(p, L.keys_out, L.vals_out, L.partial, pad_dim(e->dim), vec16, lanes, s);
+}
+
+static int backward_phases(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld, const dlrm_sparse_opt *opt,
+                           void *d_workspace, size_t workspace_bytes, int phases, dlrm_stream_t stream) {
+    if (int rc = validate_embbag(e)) return rc;
+    const bool apply = (phases & 2) != 0;
+    if (apply) {
+        DLRM_REQUIRE(opt != nullptr, "opt is NULL");
+        DLRM_REQUIRE(opt->optimizer == DLRM_OPT_SGD || opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE, "optimizer %d",
+                     opt->optimizer);
+        DLRM_REQUIRE(opt->dup_mode == DLRM_DUP_ACCUMULATE || opt->dup_mode == DLRM_DUP_LAST_WINS, "dup_mode %d",
+                     opt->dup_mode);
+        DLRM_REQUIRE(opt->optimizer != DLRM_OPT_ADAGRAD_ROWWISE || opt->d_opt_state != nullptr,
+                     "row-wise Adagrad needs d_opt_state");
+    }
+    const int64_t n_bags = (int64_t)e->num_tables * e->batch;
+    if (n_bags == 0 || e->n_indices == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_workspace != nullptr && (!apply || d_grad != nullptr), "d_grad / d_workspace is NULL");
+    DLRM_REQUIRE(!apply || grad_ld >= (int64_t)e->num_tables * e->dim, "grad_ld too small");
+    DLRM_REQUIRE(n_bags < (1ll << 31) && e->n_indices < (1ll << 40), "batch too large for 32-bit bag ids");
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_workspace) % 256 == 0, "workspace must be 256-byte aligned");
+
+    BwdParams p;
+    p.w = e->d_weight; p.tro = e->d_table_row_offsets; p.total_rows = e->total_rows;
+    p.T = e->num_tables; p.D = e->dim; p.idx = e->d_indices; p.off = e->d_offsets;
+    p.n_idx = e->n_indices; p.B = e->batch; p.n_bags = n_bags;
+    p.include_last = e->include_last_offset; p.mean = e->pooling == DLRM_POOL_MEAN;
+    p.grad = d_grad; p.grad_ld = grad_ld; p.err = e->d_error_flag; p.shard = e->d_shard_row_begin;
+    p.last_wins = apply && opt->dup_mode == DLRM_DUP_LAST_WINS;
+    p.adagrad = apply && opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE;
+    p.lr = apply ? opt->lr : 0.f; p.eps = apply ? opt->eps : 0.f; p.state = apply ? opt->d_opt_state : nullptr;
+
+    const int esz = e->row_dtype == DLRM_F32 ? 4 : 2;
+    const int nf = 16 / esz;
+    const bool vec16 = (e->dim % nf == 0) && (reinterpret_cast<uintptr_t>(e->d_weight) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(d_grad) % 16 == 0) && (grad_ld % 4 == 0) && (e->dim % 4 == 0);
+    const int lanes = vec16 ? e->dim / nf : e->dim;
+    DLRM_REQUIRE(lanes <= 256 && e->dim <= 1024, "dim=%d is too wide for this kernel (max 1024)", e->dim);
+
+    hipStream_t s = as_stream(stream);
+    const bool k64 = key_bits(e->total_rows) > 32;
+    const bool i64 = e->idx_dtype == DLRM_I64;
+    if (k64) {
+        if (i64) return run_backward<int64_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, phases, s);
+        return run_backward<int32_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, phases, s);
+    }
+    if (i64) return run_backward<int64_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, phases, s);
+    return run_backward<int32_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, phases, s);
 }
 
 }  // namespace dlrm
@@ -623,45 +676,16 @@ extern "C" int dlrm_embbag_backward_workspace_bytes(const dlrm_embbag *e, size_t
 extern "C" int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld,
                                            const dlrm_sparse_opt *opt, void *d_workspace, size_t workspace_bytes,
                                            dlrm_stream_t stream) {
-    if (int rc = validate_embbag(e)) return rc;
-    DLRM_REQUIRE(opt != nullptr, "opt is NULL");
-    DLRM_REQUIRE(opt->optimizer == DLRM_OPT_SGD || opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE, "optimizer %d",
-                 opt->optimizer);
-    DLRM_REQUIRE(opt->dup_mode == DLRM_DUP_ACCUMULATE || opt->dup_mode == DLRM_DUP_LAST_WINS, "dup_mode %d",
-                 opt->dup_mode);
-    DLRM_REQUIRE(opt->optimizer != DLRM_OPT_ADAGRAD_ROWWISE || opt->d_opt_state != nullptr,
-                 "row-wise Adagrad needs d_opt_state");
-    const int64_t n_bags = (int64_t)e->num_tables * e->batch;
-    if (n_bags == 0 || e->n_indices == 0) return DLRM_OK;
-    DLRM_REQUIRE(d_grad != nullptr && d_workspace != nullptr, "d_grad / d_workspace is NULL");
-    DLRM_REQUIRE(grad_ld >= (int64_t)e->num_tables * e->dim, "grad_ld too small");
-    DLRM_REQUIRE(n_bags < (1ll << 31) && e->n_indices < (1ll << 40), "batch too large for 32-bit bag ids");
-    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_workspace) % 256 == 0, "workspace must be 256-byte aligned");
+    return backward_phases(e, d_grad, grad_ld, opt, d_workspace, workspace_bytes, 3, stream);
+}
 
-    BwdParams p;
-    p.w = e->d_weight; p.tro = e->d_table_row_offsets; p.total_rows = e->total_rows;
-    p.T = e->num_tables; p.D = e->dim; p.idx = e->d_indices; p.off = e->d_offsets;
-    p.n_idx = e->n_indices; p.B = e->batch; p.n_bags = n_bags;
-    p.include_last = e->include_last_offset; p.mean = e->pooling == DLRM_POOL_MEAN;
-    p.grad = d_grad; p.grad_ld = grad_ld; p.err = e->d_error_flag; p.shard = e->d_shard_row_begin;
-    p.last_wins = opt->dup_mode == DLRM_DUP_LAST_WINS;
-    p.adagrad = opt->optimizer == DLRM_OPT_ADAGRAD_ROWWISE;
-    p.lr = opt->lr; p.eps = opt->eps; p.state = opt->d_opt_state;
+extern "C" int dlrm_embbag_backward_prepare(const dlrm_embbag *e, void *d_workspace, size_t workspace_bytes,
+                                            dlrm_stream_t stream) {
+    return backward_phases(e, nullptr, 0, nullptr, d_workspace, workspace_bytes, 1, stream);
+}
 
-    const int esz = e->row_dtype == DLRM_F32 ? 4 : 2;
-    const int nf = 16 / esz;
-    const bool vec16 = (e->dim % nf == 0) && (reinterpret_cast<uintptr_t>(e->d_weight) % 16 == 0) &&
-                       (reinterpret_cast<uintptr_t>(d_grad) % 16 == 0) && (grad_ld % 4 == 0) && (e->dim % 4 == 0);
-    const int lanes = vec16 ? e->dim / nf : e->dim;
-    DLRM_REQUIRE(lanes <= 256 && e->dim <= 1024, "dim=%d is too wide for this kernel (max 1024)", e->dim);
-
-    hipStream_t s = as_stream(stream);
-    const bool k64 = key_bits(e->total_rows) > 32;
-    const bool i64 = e->idx_dtype == DLRM_I64;
-    if (k64) {
-        if (i64) return run_backward<int64_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
-        return run_backward<int32_t, uint64_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
-    }
-    if (i64) return run_backward<int64_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
-    return run_backward<int32_t, uint32_t>(e, p, d_workspace, workspace_bytes, vec16, lanes, s);
+extern "C" int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld,
+                                          const dlrm_sparse_opt *opt, void *d_workspace, size_t workspace_bytes,
+                                          dlrm_stream_t stream) {
+    return backward_phases(e, d_grad, grad_ld, opt, d_workspace, workspace_bytes, 2, stream);
 }

@@ -107,6 +107,36 @@ extern "C" int dlrm_plan_add_embbag_backward_update(dlrm_plan *p, const dlrm_emb
                });
 }
 
+extern "C" int dlrm_plan_add_embbag_backward_prepare(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first,
+                                                     void *d_workspace, size_t workspace_bytes) {
+    PLAN_REQUIRE(p != nullptr && e != nullptr && offsets_first >= 0, "bad arguments");
+    const dlrm_embbag d = *e;
+    return add(p, DLRM_OP_EMBBAG_BACKWARD_PREPARE,
+               [d, offsets_first, d_workspace, workspace_bytes](dlrm_plan *pl, hipStream_t s) {
+                   dlrm_embbag x = d;
+                   x.d_indices = pl->d_indices;
+                   x.d_offsets = static_cast<const char *>(pl->d_offsets) + offsets_first * idx_size(d.idx_dtype);
+                   x.n_indices = pl->n_indices;
+                   return dlrm_embbag_backward_prepare(&x, d_workspace, workspace_bytes, s);
+               });
+}
+
+extern "C" int dlrm_plan_add_embbag_backward_apply(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first,
+                                                   const float *d_grad, int64_t grad_ld, const dlrm_sparse_opt *opt,
+                                                   void *d_workspace, size_t workspace_bytes) {
+    PLAN_REQUIRE(p != nullptr && e != nullptr && opt != nullptr && offsets_first >= 0, "bad arguments");
+    const dlrm_embbag d = *e;
+    const dlrm_sparse_opt o = *opt;
+    return add(p, DLRM_OP_EMBBAG_BACKWARD_APPLY,
+               [d, o, offsets_first, d_grad, grad_ld, d_workspace, workspace_bytes](dlrm_plan *pl, hipStream_t s) {
+                   dlrm_embbag x = d;
+                   x.d_indices = pl->d_indices;
+                   x.d_offsets = static_cast<const char *>(pl->d_offsets) + offsets_first * idx_size(d.idx_dtype);
+                   x.n_indices = pl->n_indices;
+                   return dlrm_embbag_backward_apply(&x, d_grad, grad_ld, &o, d_workspace, workspace_bytes, s);
+               });
+}
+
 extern "C" int dlrm_plan_add_linear_forward(dlrm_plan *p, const dlrm_linear *l) {
     PLAN_REQUIRE(p != nullptr && l != nullptr, "bad arguments");
     const dlrm_linear d = *l;

@@ -173,7 +173,7 @@ class MLPStack:
 class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
                  seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
-                 cache_rows_per_page=1, replay=False):
+                 cache_rows_per_page=1, replay=False, presort=None):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
@@ -289,6 +289,11 @@ class DLRM:
         self.loss = torch.zeros(1, **f32)
         self.ws_dense = None
         self.ws_sparse = None
+        # The sparse update's sort needs the ids only: it is queued on its own stream at the start of the
+        # step and runs beside the forward pass (presort; on by default on the GPU).
+        self.presort = (self.dev.type == "cuda") if presort is None else bool(presort)
+        self.prep = torch.cuda.Stream(device=dev) if (self.presort and self.dev.type == "cuda") else None
+        self.ws_sparse_rw = None
         self.replay = bool(replay) and self.dev.type == "cuda"
         self._plan, self._plan_items, self._plan_key = None, None, None
         self.plan_timing_runs = 0       # > 0: the recorded step times every entry (bench.py)
@@ -414,6 +419,24 @@ class DLRM:
             items.append(("ops", "emb", lambda: ops.copy_2d_(self.feat[:, c0:c0 + self.Trw * D], self.rw_local)))
         return items
 
+    def _presort_items(self, indices, offsets):
+        """First half of the sparse update for this rank's tables (ids only), on the "prep" stream."""
+        if not self.presort:
+            return []
+        items = [("wait", "prep", "main")]
+
+        def prep_tw():
+            self.ws_sparse = ops.embbag_backward_prepare(workspace=self.ws_sparse, **self._emb_kwargs(indices, offsets))
+
+        def prep_rw():
+            self.ws_sparse_rw = ops.embbag_backward_prepare(workspace=self.ws_sparse_rw,
+                                                            **self._rw_kwargs(indices, offsets))
+        if self.Tl:
+            items.append(("ops", "prep", prep_tw))
+        if self.Trw and self.world > 1:
+            items.append(("ops", "prep", prep_rw))
+        return items
+
     def _emb_backward_items(self, indices, offsets):
         """autograd of embedding_bag + optimizer step + write-back
         (src/dlrmtest.cpp:531-535) fused: gradients of the pooled vectors go
@@ -421,18 +444,24 @@ class DLRM:
         D, B = self.cfg.dim, self.B
         cfg = self.cfg
 
-        def update(kwargs_fn, grad, grad_ld):
+        def update(kwargs_fn, grad, grad_ld, rw=False):
+            kw = dict(lr=cfg.lr, eps=cfg.eps, opt_state=self.opt_state,
+                      optimizer=_capi.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else _capi.OPT_SGD)
+
             def run():
-                self.ws_sparse = ops.embbag_backward_update(
-                    grad=grad, grad_ld=grad_ld, workspace=self.ws_sparse, lr=cfg.lr, eps=cfg.eps,
-                    opt_state=self.opt_state,
-                    optimizer=_capi.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else _capi.OPT_SGD,
-                    **kwargs_fn(indices, offsets))
+                if self.presort:       # the occurrences were sorted at the start of the step
+                    ops.embbag_backward_apply(grad=grad, grad_ld=grad_ld,
+                                              workspace=self.ws_sparse_rw if rw else self.ws_sparse,
+                                              **kw, **kwargs_fn(indices, offsets))
+                else:
+                    self.ws_sparse = ops.embbag_backward_update(grad=grad, grad_ld=grad_ld, workspace=self.ws_sparse,
+                                                                **kw, **kwargs_fn(indices, offsets))
             return run
+        items = [("wait", "emb", "prep")] if self.presort else []
         if self.world == 1:
-            return [("ops", "emb", update(self._emb_kwargs, self.dfeat[:, self.emb_col0:], self.dfeat.stride(0)))]
+            return items + [("ops", "emb", update(self._emb_kwargs, self.dfeat[:, self.emb_col0:],
+                                                  self.dfeat.stride(0)))]
         import torch.distributed as dist
-        items = []
 
         def pack():
             o = 0
@@ -454,13 +483,14 @@ class DLRM:
             c0 = self.emb_col0 + self.plan.n_table_wise * D
             items.append(("ops", "emb", lambda: ops.copy_2d_(self.rw_local, self.dfeat[:, c0:c0 + self.Trw * D])))
             items.append(("host", "emb", lambda: dist.all_gather_into_tensor(self.rw_part, self.rw_local, group=self.pg)))
-            items.append(("ops", "emb", update(self._rw_kwargs, self.rw_part, self.Trw * D)))
+            items.append(("ops", "emb", update(self._rw_kwargs, self.rw_part, self.Trw * D, rw=True)))
         return items
 
-    def _forward_items(self, indices, offsets):
+    def _forward_items(self, indices, offsets, train=False):
         """Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
         cfg = self.cfg
-        items = [("wait", "emb", "main")]        # earlier readers of feat and the input copies are done
+        items = self._presort_items(indices, offsets) if train else []
+        items.append(("wait", "emb", "main"))    # earlier readers of feat and the input copies are done
         items += self._emb_forward_items(indices, offsets)
         items.append(("ops", "main", lambda: self.bottom.forward(self.x_dense[:, :cfg.dense_in], self.bot_acts)))
         items.append(("wait", "main", "emb"))
@@ -476,7 +506,7 @@ class DLRM:
     def _train_items(self, indices, offsets):
         """One iteration of the reference's loop body (src/dlrmtest.cpp:505-535)."""
         cfg = self.cfg
-        items = self._forward_items(indices, offsets)
+        items = self._forward_items(indices, offsets, train=True)
 
         def loss_and_top_backward():
             if cfg.loss == "bce":
@@ -517,7 +547,8 @@ class DLRM:
 
     def _streams(self):
         main = torch.cuda.current_stream() if self.dev.type == "cuda" else None
-        return {"main": main, "emb": self.side if self.side is not None else main}
+        return {"main": main, "emb": self.side if self.side is not None else main,
+                "prep": self.prep if self.prep is not None else main}
 
     def _run_items(self, items, plan=None):
         """Executes a schedule.  Without a plan the "ops" items launch their operators now; with one,

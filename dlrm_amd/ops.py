@@ -160,6 +160,42 @@ def embbag_backward_update(weight, indices, offsets, batch, grad, num_tables=1, 
     return workspace
 
 
+@_op
+def embbag_backward_prepare(weight, indices, offsets, batch, num_tables=1, table_row_offsets=None,
+                            pooling=_capi.POOL_SUM, include_last_offset=False, workspace=None, error_flag=None,
+                            shard_row_begin=None):
+    """First half of embbag_backward_update: occurrences sorted by row into the workspace (needs the ids
+    only).  Returns the workspace that embbag_backward_apply must be given."""
+    d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, pooling,
+                         include_last_offset, error_flag, shard_row_begin)
+    need = embbag_backward_workspace_bytes(d)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=weight.device)
+    _emit("embbag_backward_prepare", d, _ptr(workspace), C.c_size_t(workspace.numel()))
+    return workspace
+
+
+@_op
+def embbag_backward_apply(weight, indices, offsets, batch, grad, workspace, num_tables=1, table_row_offsets=None,
+                          pooling=_capi.POOL_SUM, include_last_offset=False, optimizer=_capi.OPT_SGD,
+                          dup_mode=_capi.DUP_ACCUMULATE, lr=0.01, eps=1e-8, opt_state=None, grad_ld=None,
+                          error_flag=None, shard_row_begin=None):
+    """Second half: reduce the gradients over the prepared order and update the rows."""
+    d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, pooling,
+                         include_last_offset, error_flag, shard_row_begin)
+    _require_cuda(grad, opt_state, workspace)
+    assert grad.dtype == torch.float32
+    if grad_ld is None:
+        assert grad.dim() == 2 and grad.is_contiguous()
+        grad_ld = grad.shape[1]
+    o = SparseOpt()
+    o.optimizer, o.dup_mode, o.lr, o.eps = optimizer, dup_mode, lr, eps
+    o.d_opt_state = 0 if opt_state is None else opt_state.data_ptr()
+    _emit("embbag_backward_apply", d, _ptr(grad), C.c_int64(grad_ld), o, _ptr(workspace),
+          C.c_size_t(workspace.numel()))
+    return workspace
+
+
 # ------------------------------------------------------------------ dense
 
 

@@ -18,7 +18,8 @@ from . import _capi, ops
 from ._capi import check
 
 OP_NAMES = ("embbag_forward", "embbag_backward_update", "linear_forward", "linear_backward_data",
-            "linear_backward_weight", "sgd_step", "interact_dot_forward", "interact_dot_backward", "loss", "copy_2d")
+            "linear_backward_weight", "sgd_step", "interact_dot_forward", "interact_dot_backward", "loss", "copy_2d",
+            "embbag_backward_prepare", "embbag_backward_apply")
 
 
 class StepPlan:
@@ -103,7 +104,7 @@ class StepRecorder:
                 cargs.append(C.byref(a))
             else:
                 cargs.append(a)
-        if name in ("embbag_forward", "embbag_backward_update"):
+        if name in ("embbag_forward", "embbag_backward_update", "embbag_backward_prepare", "embbag_backward_apply"):
             d = args[0]
             if d.d_indices != self.indices.data_ptr():
                 raise RuntimeError("a recorded EmbeddingBag call must use the batch's index tensor")

@@ -51,7 +51,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1003
+#define DLRM_ABI_VERSION 1004
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -146,6 +146,16 @@ int dlrm_embbag_backward_workspace_bytes(const dlrm_embbag *e, size_t *bytes);
 int dlrm_embbag_backward_update(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld,
                                 const dlrm_sparse_opt *opt, void *d_workspace,
                                 size_t workspace_bytes, dlrm_stream_t stream);
+/*
+ * The same in two halves.  _prepare needs the ids only (occurrences expanded and sorted by row into the
+ * workspace), so it can run as soon as a batch's ids are on the device -- beside the forward pass, on
+ * another stream.  _apply reduces the gradients over the sorted occurrences and updates the rows; it
+ * must follow a _prepare with the same descriptor fields (ids, offsets, tables) and workspace.
+ */
+int dlrm_embbag_backward_prepare(const dlrm_embbag *e, void *d_workspace, size_t workspace_bytes,
+                                 dlrm_stream_t stream);
+int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_t grad_ld, const dlrm_sparse_opt *opt,
+                               void *d_workspace, size_t workspace_bytes, dlrm_stream_t stream);
 
 /* ------------------------------------------------------------- dense MLP */
 
@@ -341,7 +351,8 @@ typedef struct dlrm_plan dlrm_plan;
 enum {
     DLRM_OP_EMBBAG_FORWARD = 0, DLRM_OP_EMBBAG_BACKWARD_UPDATE = 1, DLRM_OP_LINEAR_FORWARD = 2,
     DLRM_OP_LINEAR_BACKWARD_DATA = 3, DLRM_OP_LINEAR_BACKWARD_WEIGHT = 4, DLRM_OP_SGD_STEP = 5,
-    DLRM_OP_INTERACT_DOT_FORWARD = 6, DLRM_OP_INTERACT_DOT_BACKWARD = 7, DLRM_OP_LOSS = 8, DLRM_OP_COPY_2D = 9
+    DLRM_OP_INTERACT_DOT_FORWARD = 6, DLRM_OP_INTERACT_DOT_BACKWARD = 7, DLRM_OP_LOSS = 8, DLRM_OP_COPY_2D = 9,
+    DLRM_OP_EMBBAG_BACKWARD_PREPARE = 10, DLRM_OP_EMBBAG_BACKWARD_APPLY = 11
 };
 int dlrm_plan_create(dlrm_plan **out);
 int dlrm_plan_destroy(dlrm_plan *p);
@@ -353,6 +364,11 @@ int dlrm_plan_add_embbag_forward(dlrm_plan *p, const dlrm_embbag *e, int64_t off
 int dlrm_plan_add_embbag_backward_update(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first,
                                          const float *d_grad, int64_t grad_ld, const dlrm_sparse_opt *opt,
                                          void *d_workspace, size_t workspace_bytes);
+int dlrm_plan_add_embbag_backward_prepare(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first, void *d_workspace,
+                                          size_t workspace_bytes);
+int dlrm_plan_add_embbag_backward_apply(dlrm_plan *p, const dlrm_embbag *e, int64_t offsets_first, const float *d_grad,
+                                        int64_t grad_ld, const dlrm_sparse_opt *opt, void *d_workspace,
+                                        size_t workspace_bytes);
 int dlrm_plan_add_linear_forward(dlrm_plan *p, const dlrm_linear *l);
 int dlrm_plan_add_linear_backward_data(dlrm_plan *p, const dlrm_linear_bwd *l);
 int dlrm_plan_add_linear_backward_weight(dlrm_plan *p, const dlrm_linear_bwd *l, void *d_workspace,
