@@ -43,6 +43,8 @@ def gemm(shapes=None):
         x = torch.randn(M, pad(pad4(K)), device="cuda")[:, :K]
         w = torch.randn(N, pad(pad4(K)), device="cuda")[:, :K]
         b = torch.randn(N, device="cuda")
+        if os.environ.get("GEMM_ZERO"):      # operands of zeros: how much of the time is data-dependent power?
+            x.zero_(); w.zero_()
         y = torch.empty(M, pad(pad4(N)), device="cuda")[:, :N]
         dz = torch.randn(M, pad(pad4(N)), device="cuda")[:, :N]
         dx = torch.empty(M, pad(pad4(K)), device="cuda")[:, :K]
