@@ -47,6 +47,11 @@ def gemm(shapes=None):
             x.zero_(); w.zero_()
         y = torch.empty(M, pad(pad4(N)), device="cuda")[:, :N]
         dz = torch.randn(M, pad(pad4(N)), device="cuda")[:, :N]
+        if os.environ.get("GEMM_RAWBF16"):   # every 16-bit half of the operands is a sane random bf16 value
+            for t in (x, w, dz):
+                base = t._base if t._base is not None else t
+                raw = torch.randn(base.shape[0], base.shape[1] * 2, device="cuda").to(torch.bfloat16)
+                base.copy_(raw.view(torch.float32))
         dx = torch.empty(M, pad(pad4(K)), device="cuda")[:, :K]
         dw = torch.empty(N, pad(pad4(K)), device="cuda")[:, :K]
         db = torch.empty(N, device="cuda")
