@@ -155,7 +155,18 @@ def main():
                     help="launch every operator from Python instead of replaying the recorded step (dlrm_plan)")
     ap.add_argument("--replay", action="store_true",
                     help="N>1: replay the recorded step too (default there is eager; one GPU replays by default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: embedding side on the caller's stream")
+    ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")
+    ap.add_argument("--progress", action="store_true", help="synchronise and print a line to stderr after every step")
+    ap.add_argument("--watchdog", type=int, default=0,
+                    help="seconds after which a run that has not finished dumps every thread's stack and exits")
     args = ap.parse_args()
+    if args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not args.replay:
@@ -166,13 +177,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from dlrm_amd import ops
     from dlrm_amd.data import synthetic_batch
@@ -197,7 +213,8 @@ def main():
     cached = args.cache_fraction > 0
     model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan,
                  cache_fraction=args.cache_fraction if cached else None,
-                 cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager)
+                 cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager,
+                 overlap=False if args.no_overlap else None, presort=False if args.no_presort else None)
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled
@@ -224,13 +241,19 @@ def main():
         model_ref["unique_rows"], model_ref["unique_rows_rw"] = uniq, uniq_rw
         model.load_batch(dense, labels)
         if cached and not args.no_prefetch:
-            return model.train_step(idx, off, next_indices=batches[(i + 1) % n_batches][1])
-        return model.train_step(idx, off)
+            out = model.train_step(idx, off, next_indices=batches[(i + 1) % n_batches][1])
+        else:
+            out = model.train_step(idx, off)
+        if args.progress:
+            torch.cuda.synchronize()
+            print("[rank %d] step %d done at %.2f s" % (rank, i, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+        return out
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
+    t_start = time.perf_counter()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -91,16 +91,30 @@ struct BwdParams {
     const int64_t *shard;  // first global row held per table (row-wise shard), or NULL
 };
 
-// lanes_per_bag lanes walk the positions of one bag
+constexpr int kTailBlocks = 16;
+
+// lanes_per_bag lanes walk the positions of one bag (workgroups [0, bag_blocks)).  The index array may
+// be longer than the range the offsets address (a descriptor for some of the tables of a batch):
+// the kTailBlocks workgroups behind bag_blocks give every position outside that range the key that
+// the update skips, so the sort never sees what an earlier call left in the workspace.
 template <typename IDX, typename KEY>
-__global__ __launch_bounds__(kBwdThreads) void expand_pairs_kernel(BwdParams p, int lanes_per_bag, KEY *keys,
-                                                                    int32_t *vals) {
+__global__ __launch_bounds__(kBwdThreads) void expand_pairs_kernel(BwdParams p, int lanes_per_bag, unsigned bag_blocks,
+                                                                    KEY *keys, int32_t *vals) {
+    const IDX *off = static_cast<const IDX *>(p.off);
+    const IDX *idx = static_cast<const IDX *>(p.idx);
+    if (blockIdx.x >= bag_blocks) {
+        const int64_t lo = (int64_t)off[0];
+        const int64_t hi = p.include_last ? (int64_t)off[p.n_bags] : p.n_idx;
+        const int64_t first = (int64_t)(blockIdx.x - bag_blocks) * kBwdThreads + threadIdx.x;
+        const int64_t stride = (int64_t)kTailBlocks * kBwdThreads;
+        for (int64_t q = first; q < lo && q < p.n_idx; q += stride) { keys[q] = (KEY)p.total_rows; vals[q] = 0; }
+        for (int64_t q = (hi > 0 ? hi : 0) + first; q < p.n_idx; q += stride) { keys[q] = (KEY)p.total_rows; vals[q] = 0; }
+        return;
+    }
     const int64_t tid = (int64_t)blockIdx.x * kBwdThreads + threadIdx.x;
     const int64_t g = tid / lanes_per_bag;
     const int lane = (int)(tid % lanes_per_bag);
     if (g >= p.n_bags) return;
-    const IDX *off = static_cast<const IDX *>(p.off);
-    const IDX *idx = static_cast<const IDX *>(p.idx);
     const int64_t start = (int64_t)off[g];
     const int64_t end = (g + 1 < p.n_bags || p.include_last) ? (int64_t)off[g + 1] : p.n_idx;
     const int t = (int)((uint32_t)g / (uint32_t)p.B);
@@ -591,8 +605,8 @@ static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_
         int lpb = 1;
         while (lpb < 64 && lpb * 2 <= avg_len) lpb <<= 1;
         const int64_t blocks = ceil_div(p.n_bags * lpb, kBwdThreads);
-        hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks), dim3(kBwdThreads), 0, s, p, lpb,
-                           L.keys_in, L.vals_in);
+        hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks + kTailBlocks), dim3(kBwdThreads), 0, s,
+                           p, lpb, (unsigned)blocks, L.keys_in, L.vals_in);
         DLRM_LAUNCH_CHECK();
         size_t tmp = L.sort_tmp_bytes;
         DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,

@@ -18,6 +18,8 @@ The MLPs are data parallel and their gradients are summed with one all-reduce
 of a single flat buffer.  Losses are means over the global batch, so per-rank
 gradients simply add.
 """
+import os
+import sys
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -364,11 +366,44 @@ class DLRM:
                     table_row_offsets=self.table_row_offsets[self.Tl:], pooling=self.pooling,
                     include_last_offset=True, error_flag=self.err_flag, shard_row_begin=self.shard_row_begin)
 
+    # Collectives.  RCCL works on device buffers in stream order.  gloo is the rehearsal backend (CPU ranks,
+    # or several ranks sharing one GPU): device buffers are staged through host memory there.
+    def _staged(self):
+        import torch.distributed as dist
+        return self.dev.type == "cuda" and dist.get_backend(self.pg) == "gloo"
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        import torch.distributed as dist
+        if self._staged():
+            h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, h_in, out_splits, in_splits, group=self.pg)
+            out.copy_(h_out)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
+
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+        if self._staged():
+            h = t.cpu()
+            dist.all_reduce(h, group=self.pg)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.pg)
+
+    def _all_gather(self, out, inp):
+        import torch.distributed as dist
+        if self._staged():
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h_out, inp.cpu(), group=self.pg)
+            out.copy_(h_out)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.pg)
+
     def _reduce_scatter_batch(self, out, inp):
         """out [B, C] = sum over ranks of their inp [Bg, C] rows of this rank's batch slice."""
         import torch.distributed as dist
-        if dist.get_backend(self.pg) == "gloo":       # no reduce-scatter there: CPU rehearsal only
-            dist.all_reduce(inp, group=self.pg)
+        if dist.get_backend(self.pg) == "gloo":       # no reduce-scatter there
+            self._all_reduce(inp)
             out.copy_(inp[self.rank * self.B:(self.rank + 1) * self.B])
         else:
             dist.reduce_scatter_tensor(out, inp, group=self.pg)
@@ -397,8 +432,8 @@ class DLRM:
         if self.Tl:
             items.append(("ops", "emb", lambda: ops.embbag_forward(out=self.a2a_send, out_ld=self.Tl * D,
                                                                    **self._emb_kwargs(indices, offsets))))
-        items.append(("host", "emb", lambda: dist.all_to_all_single(
-            self.a2a_recv[:n_recv], self.a2a_send[:n_send], self.recv_splits, self.send_splits, group=self.pg)))
+        items.append(("host", "emb", lambda: self._all_to_all(
+            self.a2a_recv[:n_recv], self.a2a_send[:n_send], self.recv_splits, self.send_splits)))
 
         def unpack():
             o = 0
@@ -475,14 +510,14 @@ class DLRM:
         n_send, n_recv = self.Bg * self.Tl * D, B * self.plan.n_table_wise * D
         if self.plan.n_table_wise:
             items.append(("ops", "emb", pack))
-        items.append(("host", "emb", lambda: dist.all_to_all_single(
-            self.g_recv[:n_send], self.g_send[:n_recv], self.send_splits, self.recv_splits, group=self.pg)))
+        items.append(("host", "emb", lambda: self._all_to_all(
+            self.g_recv[:n_send], self.g_send[:n_recv], self.send_splits, self.recv_splits)))
         if self.Tl:
             items.append(("ops", "emb", update(self._emb_kwargs, self.g_recv, self.Tl * D)))
         if self.Trw:
             c0 = self.emb_col0 + self.plan.n_table_wise * D
             items.append(("ops", "emb", lambda: ops.copy_2d_(self.rw_local, self.dfeat[:, c0:c0 + self.Trw * D])))
-            items.append(("host", "emb", lambda: dist.all_gather_into_tensor(self.rw_part, self.rw_local, group=self.pg)))
+            items.append(("host", "emb", lambda: self._all_gather(self.rw_part, self.rw_local)))
             items.append(("ops", "emb", update(self._rw_kwargs, self.rw_part, self.Trw * D, rw=True)))
         return items
 
@@ -541,7 +576,7 @@ class DLRM:
         items.append(("wait", "main", "emb"))     # rows are updated before anyone reuses dfeat
         if self.world > 1:
             import torch.distributed as dist
-            items.append(("host", "main", lambda: dist.all_reduce(self.grads, group=self.pg)))
+            items.append(("host", "main", lambda: self._all_reduce(self.grads)))
         items.append(("ops", "main", lambda: ops.sgd_step_(self.params, self.grads, cfg.lr)))
         return items
 
@@ -554,7 +589,12 @@ class DLRM:
         """Executes a schedule.  Without a plan the "ops" items launch their operators now; with one,
         every "ops" item is a pair (first, last) of recorded entries replayed by one C call."""
         st = self._streams()
-        for kind, a, b in items:
+        trace = os.environ.get("DLRM_TRACE_ITEMS")      # debugging aid: synchronise and report after every item
+        for n, (kind, a, b) in enumerate(items):
+            if trace:
+                if n:
+                    torch.cuda.synchronize()
+                print("[rank %d] item %d/%d %s %s" % (self.rank, n, len(items), kind, a), file=sys.stderr, flush=True)
             if kind == "wait":
                 if st[a] is not None and st[a] != st[b]:
                     st[a].wait_stream(st[b])

@@ -98,8 +98,10 @@ typedef struct dlrm_embbag {
     int32_t row_dtype;           /* DLRM_F32 | DLRM_BF16 */
     int32_t idx_dtype;           /* DLRM_I32 | DLRM_I64 */
     const void *d_indices;       /* idx[n_indices] */
-    const void *d_offsets;       /* idx[T*batch] (+1 when include_last_offset) */
-    int64_t n_indices;
+    const void *d_offsets;       /* idx[T*batch] (+1 when include_last_offset): positions in d_indices.  With */
+                                 /* include_last_offset the bags may address a part of a longer index array */
+                                 /* (a descriptor for some of a batch's tables); the rest is ignored */
+    int64_t n_indices;           /* length of d_indices */
     int64_t batch;
     int32_t include_last_offset;
     int32_t pooling;             /* DLRM_POOL_SUM | DLRM_POOL_MEAN */

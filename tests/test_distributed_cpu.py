@@ -73,14 +73,19 @@ def _cfg(kind):
                       loss="mse", final_relu=True, pooling="mean", lookups=3, lr=0.02)
 
 
-def _worker(rank, world, port, kind, ret):
+def _worker(rank, world, port, kind, ret, device="cpu", replay=False):
+    """device "cpu": the CPU oracle stands in for dlrm_amd.ops.  device "cuda": the ranks share GPU 0 and run
+    the HIP kernels; gloo moves the buffers through host memory (RCCL refuses two ranks on one device)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dlrm_amd import ops
-        from tests import cpu_ops_shim
-        cpu_ops_shim.install(ops)
+        if device == "cpu":
+            from tests import cpu_ops_shim
+            cpu_ops_shim.install(ops)
+        else:
+            torch.cuda.set_device(0)
         from dlrm_amd.model import DLRM
         from oracle import oracle as orc
         from tests.oracle_model import make_batch, oracle_train_step
@@ -94,7 +99,10 @@ def _worker(rank, world, port, kind, ret):
         if hybrid:   # the two biggest tables are split by rows, the rest placed whole
             plan = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=60 if kind == "dot" else 40)
             assert len(plan.row_wise) == 2
-        m = DLRM(cfg, Bl, device="cpu", rank=rank, world=world, seed=4, plan=plan)
+        m = DLRM(cfg, Bl, device=device, rank=rank, world=world, seed=4, plan=plan, replay=replay)
+        dev = m.dev
+        host = lambda t: t.detach().cpu().numpy()
+        loose = 1.0 if device == "cpu" else 10.0      # float32 MFMA products vs the oracle's double accumulation
         if kind == "cat":
             for b in m.bottom.b + m.top.b:
                 b.abs_()
@@ -102,10 +110,14 @@ def _worker(rank, world, port, kind, ret):
         # single-process reference state: all tables (global order), same dense parameters
         tables = [orc.table_init_uniform(r * cfg.dim, (4 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
                   for t, r in enumerate(cfg.table_rows)]
-        Ws = [w.numpy().copy() for w in m.bottom.W + m.top.W]
-        bs = [b.numpy().copy() for b in m.bottom.b + m.top.b]
-        ok = True
-        for step in range(2):
+        Ws = [host(w).copy() for w in m.bottom.W + m.top.W]
+        bs = [host(b).copy() for b in m.bottom.b + m.top.b]
+        bad = []
+
+        def close(name, a, r, rtol, atol):
+            if not np.allclose(a, r, rtol=rtol, atol=atol):
+                bad.append("%s step %d: max err %.3g (max |ref| %.3g)" % (name, step, np.abs(a - r).max(), np.abs(r).max()))
+        for step in range(3 if replay else 2):           # replay: record, replay, replay with new ids
             dense, idx, off, labels = make_batch(rng, cfg, Bg)
             L = cfg.lookups
             # this rank's tables over the global batch
@@ -113,21 +125,21 @@ def _worker(rank, world, port, kind, ret):
             idx_l = np.concatenate([idx[t * Bg * L:(t + 1) * Bg * L] for t in my]) if my else np.zeros(0, np.int64)
             off_l = np.arange(len(my) * Bg + 1, dtype=np.int64) * L
             sl = slice(rank * Bl, (rank + 1) * Bl)
-            m.load_batch(torch.from_numpy(dense[sl]), torch.from_numpy(labels[sl]))
-            loss = m.train_step(torch.from_numpy(idx_l), torch.from_numpy(off_l))
-            tot = loss.clone()
+            m.load_batch(torch.from_numpy(dense[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev))
+            loss = m.train_step(torch.from_numpy(idx_l).to(dev), torch.from_numpy(off_l).to(dev))
+            tot = loss.detach().cpu().clone()
             dist.all_reduce(tot)                               # per-rank shares add up to the global mean
             loss_ref, pred_ref = oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
                                                    cfg.lr, feature_order=m.plan.feature_order)
-            ok &= abs(tot.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
-            ok &= np.allclose(m.pred.numpy().reshape(-1), pred_ref[sl], rtol=1e-4, atol=1e-6)
-            tro = m.table_row_offsets.numpy()
+            close("loss", np.float64(tot.item()), np.float64(loss_ref), 1e-5, 1e-7)
+            close("pred", host(m.pred).reshape(-1), pred_ref[sl], 1e-4, 1e-6 * loose)
+            tro = host(m.table_row_offsets)
             for lt, t in enumerate(my):
                 lo, hi = (0, cfg.table_rows[t]) if lt < m.Tl else m.plan.row_range(t, rank)
-                ok &= np.allclose(m.weight[tro[lt]:tro[lt + 1]].numpy(), tables[t][lo:hi], rtol=1e-5, atol=1e-6)
-            for a, r in zip(m.bottom.W + m.top.W + m.bottom.b + m.top.b, Ws + bs):
-                ok &= np.allclose(a.numpy(), r, rtol=1e-4, atol=1e-6)
-        ret[rank] = bool(ok)
+                close("table %d" % t, host(m.weight[tro[lt]:tro[lt + 1]]), tables[t][lo:hi], 1e-5 * loose, 1e-6)
+            for n, (a, r) in enumerate(zip(m.bottom.W + m.top.W + m.bottom.b + m.top.b, Ws + bs)):
+                close("dense parameter %d" % n, host(a), r, 1e-4, 1e-6 * loose)
+        ret[rank] = "; ".join(bad) if bad else True
     finally:
         dist.destroy_process_group()
 

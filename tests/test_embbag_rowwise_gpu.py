@@ -96,3 +96,35 @@ def test_shard_updates_match_whole_table_update(oracle, case, mode, opt):
             if d_state is not None:
                 want_s = st_ref[tro[t] + begin[t]:tro[t] + begin[t] + n]
                 assert np.allclose(d_state.cpu().numpy()[ltro[t]:ltro[t] + n], want_s, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("halves", [False, True], ids=["update", "prepare+apply"])
+def test_descriptor_for_some_tables_of_a_longer_index_array(oracle, split, halves):
+    """Two descriptors share one index / offset array (tables [0, split) and [split, T), the offsets keep
+    their positions in the whole array): the fused update of each must ignore the positions that belong
+    to the other, whatever an earlier call left in the workspace."""
+    from dlrm_amd import ops
+    T, B, D, rows_list, L = 3, 37, 32, [300, 8, 77], 4
+    rng = np.random.default_rng(91 + split)
+    w, tro, idx, off = make_case(rng, T, B, D, rows_list, L, True)
+    grad = rng.standard_normal((B, T * D)).astype(np.float32)
+    w_ref = w.copy()
+    oracle.embbag_backward_update(w_ref, idx, off, B, grad, T, tro, oracle.POOL_SUM, True, oracle.OPT_SGD,
+                                  oracle.DUP_ACCUMULATE, 0.05, 1e-8, None)
+    dw = torch.from_numpy(w).cuda()
+    d_idx, d_off = torch.from_numpy(idx).cuda(), torch.from_numpy(off).cuda()
+    d_tro = torch.from_numpy(tro).cuda()
+    d_grad = torch.from_numpy(grad).cuda()
+    for t0, t1 in ((0, split), (split, T)):
+        kw = dict(weight=dw, indices=d_idx, offsets=d_off[t0 * B:t1 * B + 1], batch=B, num_tables=t1 - t0,
+                  table_row_offsets=d_tro[t0:t1 + 1], pooling=oracle.POOL_SUM, include_last_offset=True)
+        ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")       # zero keys = row 0, bag 0: must not be used
+        g = d_grad[:, t0 * D:t1 * D].contiguous()
+        if halves:
+            ws = ops.embbag_backward_prepare(workspace=ws, **kw)
+            ops.embbag_backward_apply(grad=g, workspace=ws, lr=0.05, **kw)
+        else:
+            ops.embbag_backward_update(grad=g, workspace=ws, lr=0.05, **kw)
+    scale = float(np.max(np.abs(w_ref)))
+    assert np.max(np.abs(dw.cpu().numpy() - w_ref)) <= 1e-5 * scale
