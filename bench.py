@@ -153,8 +153,7 @@ def main():
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
     ap.add_argument("--eager", action="store_true",
                     help="launch every operator from Python instead of replaying the recorded step (dlrm_plan)")
-    ap.add_argument("--replay", action="store_true",
-                    help="N>1: replay the recorded step too (default there is eager; one GPU replays by default)")
+    ap.add_argument("--replay", action="store_true", help="(default) replay the recorded step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
@@ -169,8 +168,9 @@ def main():
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not args.replay:
-        args.eager = True
+    if world > 1 and not args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(900, exit=True)     # a stuck collective ends with every thread's stack
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:

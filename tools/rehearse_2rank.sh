@@ -12,6 +12,6 @@ run() {
 }
 if [ -n "$ONLY" ]; then run $ONLY; exit; fi
 run
-run --replay
+run --eager
 run --sharding hybrid --row-wise-min-rows 1000000
-run --sharding hybrid --row-wise-min-rows 1000000 --replay
+run --sharding hybrid --row-wise-min-rows 1000000 --eager
