@@ -157,7 +157,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: embedding side on the caller's stream")
+    ap.add_argument("--no-overlap", action="store_true", help="embedding side on the caller's stream")
+    ap.add_argument("--overlap", action="store_true", help="embedding side on its own stream (default for N>1)")
     ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")
     ap.add_argument("--progress", action="store_true", help="synchronise and print a line to stderr after every step")
     ap.add_argument("--watchdog", type=int, default=0,
@@ -214,7 +215,7 @@ def main():
     model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan,
                  cache_fraction=args.cache_fraction if cached else None,
                  cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager,
-                 overlap=False if args.no_overlap else None, presort=False if args.no_presort else None)
+                 overlap=False if args.no_overlap else (True if args.overlap else None), presort=False if args.no_presort else None)
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled

@@ -1,4 +1,4 @@
-"""ctypes binding of the CPU oracle (oracle/dlrm_oracle.c).
+"""ctypes binding of the CPU oracle (oracle/dlrm_oracle.c, oracle/vec_cache_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  Nothing under dlrm_amd/ imports this module.
@@ -18,8 +18,8 @@ OPT_SGD, OPT_ADAGRAD_ROWWISE = 0, 1
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "dlrm_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("dlrm_oracle.c", "vec_cache_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -41,6 +41,12 @@ def lib():
             getattr(_lib, name).restype = C.c_int64
         _lib.orc_mse_loss.restype = C.c_float
         _lib.orc_bce_logits_loss.restype = C.c_float
+        _lib.orc_veccache_create.restype = C.c_void_p
+        _lib.orc_veccache_create.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]
+        for name in ("orc_veccache_get", "orc_veccache_reclaim", "orc_veccache_page_count", "orc_veccache_list_len",
+                     "orc_veccache_pending", "orc_veccache_written_pages", "orc_veccache_fifo_order",
+                     "orc_veccache_pending_rows"):
+            getattr(_lib, name).restype = C.c_int64
     return _lib
 
 
@@ -242,3 +248,76 @@ class PageCache:
 
     def slot_of(self, table, page):
         return self.L.orc_pagecache_slot_of(self.h, table, C.c_int64(page))
+
+
+class VectorCache:
+    """Vector-granular FIFO cache over a log-structured page store (restates class cache2,
+    include/data2.h:219-287 + src/emb_cache2.cpp, as driven by src/dlrmtest2.cpp)."""
+
+    def __init__(self, num_tables, rows_per_table, dim, cache_size, page_bytes=4096, ws_opt=8):
+        self.L = lib()
+        self.T, self.rows = num_tables, rows_per_table
+        self.h = C.c_void_p(self.L.orc_veccache_create(num_tables, C.c_int64(rows_per_table), dim, page_bytes,
+                                                       ws_opt, C.c_int64(cache_size)))
+        self.vpo = self.L.orc_veccache_vpo(self.h)
+
+    def __del__(self):
+        try:
+            self.L.orc_veccache_destroy(self.h)
+        except Exception:
+            pass
+
+    def get(self, table, ids):
+        """cache2::get_emb_vectors: returns the pages read, in read order."""
+        ids = _i64(ids)
+        pages = np.empty(max(ids.size, 1), dtype=np.int64)
+        n = self.L.orc_veccache_get(self.h, table, _p(ids), C.c_int64(ids.size), _p(pages))
+        return pages[:n].copy()
+
+    def reclaim(self):
+        """reclaim_emb_cache of dlrmtest2: returns the number of Reclaim_vector_page calls."""
+        return self.L.orc_veccache_reclaim(self.h)
+
+    def reclaim_table(self, table):
+        return self.L.orc_veccache_reclaim_table(self.h, table)
+
+    def save(self, table, ids):
+        ids = _i64(ids)
+        self.L.orc_veccache_save(self.h, table, _p(ids), C.c_int64(ids.size))
+
+    @property
+    def page_count(self):
+        return self.L.orc_veccache_page_count(self.h)
+
+    def list_len(self, table):
+        return self.L.orc_veccache_list_len(self.h, table)
+
+    def pending(self, table):
+        return self.L.orc_veccache_pending(self.h, table)
+
+    def written_pages(self, table):
+        return self.L.orc_veccache_written_pages(self.h, table)
+
+    def counters(self, which, reset=False):
+        out = np.zeros(self.T, dtype=np.int64)
+        self.L.orc_veccache_counters(self.h, {"read": 0, "write": 1, "hit": 2, "miss": 3}[which], _p(out), int(reset))
+        return out
+
+    def export(self, table):
+        """(resident, listed, cnt, loc) of every vector of the table."""
+        res, lst = np.empty(self.rows, np.uint8), np.empty(self.rows, np.uint8)
+        cnt, loc = np.empty(self.rows, np.int32), np.empty(self.rows, np.int32)
+        self.L.orc_veccache_export(self.h, table, _p(res), _p(lst), _p(cnt), _p(loc))
+        return res, lst, cnt, loc
+
+    def fifo_order(self, table):
+        n = self.list_len(table)
+        out = np.empty(max(n, 1), dtype=np.int64)
+        k = self.L.orc_veccache_fifo_order(self.h, table, _p(out), C.c_int64(n))
+        return out[:k].copy()
+
+    def pending_rows(self, table):
+        n = self.pending(table)
+        out = np.empty(max(n, 1), dtype=np.int64)
+        k = self.L.orc_veccache_pending_rows(self.h, table, _p(out), C.c_int64(n))
+        return out[:k].copy()
