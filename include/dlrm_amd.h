@@ -51,7 +51,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1004
+#define DLRM_ABI_VERSION 1005
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -441,6 +441,84 @@ int dlrm_cache_state(dlrm_cache *c, dlrm_cache_state_t *h_state, dlrm_stream_t s
 int dlrm_cache_set_cache_size(dlrm_cache *c, int64_t cache_size, dlrm_stream_t stream);
 /* Slot of every page of one table (-1 = not resident) into host int32[pages of the table]. Synchronises. */
 int dlrm_cache_export_page_map(dlrm_cache *c, int32_t table, int32_t *h_out, dlrm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Vector-granular cache over a log-structured page store: the reference's second policy.
+ * Replaces class cache2 (include/data2.h:219-287, src/emb_cache2.cpp) as src/dlrmtest2.cpp drives it:
+ *   - rows are resident one by one; a table lists the rows that were asked for, oldest request first
+ *     (lru_page, src/emb_cache2.cpp:638-659: a hit counts but does not move the entry);
+ *   - a table whose list exceeds cache_size rows evicts its oldest entries (reclaim_emb_cache,
+ *     src/dlrmtest2.cpp:462-481); evicted rows collect in a buffer of evict_group * rows_per_page rows per
+ *     table, a full buffer is written as evict_group new pages (Reclaim_vector_page, src/emb_cache2.cpp:397-633);
+ *   - a missing row is read together with the page that holds it, and every row that page lists becomes
+ *     resident (cache2::read, :729-892) -- unlisted; such rows go when a listed row of their home page
+ *     (rows [p*rows_per_page, (p+1)*rows_per_page)) is evicted (:492-496).
+ * The store of table t is pinned host memory of (ceil(rows/rows_per_page) + log_pages_per_table) pages: the
+ * table itself, row-major, then the region the cache writes pages to.  Flash placement below the page
+ * (chunks, write pointers, garbage collection: src/emb_cache2.cpp:28-285) has no counterpart.
+ * ------------------------------------------------------------------------ */
+typedef struct dlrm_vcache dlrm_vcache;
+
+typedef struct dlrm_vcache_config {
+    int32_t num_tables;
+    int32_t dim;                      /* float32 rows; dim * 4 must be a multiple of 16 */
+    int32_t rows_per_page;            /* vector_page_offset = page bytes / row bytes (include/data2.h:161) */
+    int32_t evict_group;              /* ws_opt: pages per write (the reference's device reports 8) */
+    const int64_t *table_rows;        /* host int64[T] */
+    void *const *h_table_store;       /* host pointers [T], from dlrm_host_alloc, sized as described above */
+    int64_t log_pages_per_table;
+    int64_t num_slots;                /* rows of the HBM pool (listed rows + rows that came along with a page) */
+    int64_t cache_size;               /* listed rows per table (src/dlrmtest2.cpp:53, :468); >= evict_group * rows_per_page */
+    void *d_slot_pool;                /* optional caller-owned [num_slots, dim] float32 device buffer */
+} dlrm_vcache_config;
+
+typedef struct dlrm_vcache_state_t {
+    int64_t page_count;               /* cache2::page_count: only ever lowered, by evict_group per write (:614) */
+    int64_t cache_size;
+    int64_t free_slots;
+    int64_t epoch;                    /* lookups so far */
+    int64_t error_flags;              /* 1 id out of range, 2 slot pool exhausted, 8 a table's written region is full */
+    int64_t last_lookup_pages_read;
+    int64_t num_slots;
+    int64_t total_rows;
+} dlrm_vcache_state_t;
+
+/* per table: pages read, pages written (both reset by dlrm_vcache_counters(reset) like cache2::read_page /
+ * write_page, include/data2.h:263-274), ids found resident, ids not, rows evicted, rows resident now, rows
+ * listed now, unlisted rows dropped, rows waiting in the write buffer, pages written in total */
+#define DLRM_VCACHE_NUM_COUNTERS 10
+
+int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **out);
+int dlrm_vcache_destroy(dlrm_vcache *c);
+/* The slot pool [num_slots, dim]: the weight matrix for dlrm_embbag (d_table_row_offsets = NULL). */
+int dlrm_vcache_storage(dlrm_vcache *c, void **d_data, int64_t *total_rows);
+/* cache2::get_emb_vectors (src/emb_cache2.cpp:686-699) for all tables of a batch: ids of table t at
+ * [h_table_offsets[t], h_table_offsets[t+1]), in the caller's order (dlrmtest2 does not sort them,
+ * src/dlrmtest2.cpp:63-67); d_rows_out[i] = row of id i in the slot pool (same integer type as the ids). */
+int dlrm_vcache_lookup(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
+                       void *d_rows_out, dlrm_stream_t stream);
+/* reclaim_emb_cache of src/dlrmtest2.cpp:462-481.  Synchronises once (the number of listed rows sizes a sort). */
+int dlrm_vcache_reclaim(dlrm_vcache *c, dlrm_stream_t stream);
+/* save_emb (src/dlrmtest2.cpp:169-177): rows of the batch that the reclaim has dropped are made resident
+ * again, unlisted, with their current values.  d_rows_out optional (as in lookup). */
+int dlrm_vcache_restore(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
+                        void *d_rows_out, dlrm_stream_t stream);
+/* d_out[i][dim] = current value of id i, wherever it lives (slot pool, write buffer, store).  No state change. */
+int dlrm_vcache_read_rows(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
+                          float *d_out, dlrm_stream_t stream);
+/* h_out: host int64[T][DLRM_VCACHE_NUM_COUNTERS].  Synchronises. */
+int dlrm_vcache_counters(dlrm_vcache *c, int64_t *h_out, int32_t reset_read_write, dlrm_stream_t stream);
+int dlrm_vcache_state(dlrm_vcache *c, dlrm_vcache_state_t *h_state, dlrm_stream_t stream);
+int dlrm_vcache_set_cache_size(dlrm_vcache *c, int64_t cache_size, dlrm_stream_t stream);
+/* Per row of one table (any output may be NULL; host int32[rows]): slot (-1 = not resident), page that holds
+ * the stored value (initial pages first, then written pages in order), position in the write buffer (-1 =
+ * not waiting).  Synchronises. */
+int dlrm_vcache_export_table(dlrm_vcache *c, int32_t table, int32_t *h_row_slot, int32_t *h_row_page,
+                             int32_t *h_row_pending, dlrm_stream_t stream);
+/* Per slot (host arrays of num_slots entries, any may be NULL): global row, list key (0 = not listed, else
+ * (epoch << 32) | position of the first request: smaller = older), hit count.  Synchronises. */
+int dlrm_vcache_export_slots(dlrm_vcache *c, int32_t *h_slot_row, uint64_t *h_slot_key, int32_t *h_slot_count,
+                             dlrm_stream_t stream);
 
 #ifdef __cplusplus
 }
