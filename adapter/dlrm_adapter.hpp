@@ -5,6 +5,7 @@
 //
 //   reference                                   here
 //   class cache (include/data.h:242-298)        dlrm_amd::cache
+//   class cache2 (include/data2.h:219-287)      dlrm_amd::cache2   (the policy of src/dlrmtest2.cpp)
 //   struct emb  (src/dlrmtest.cpp:144-210)      dlrm_amd::emb
 //   struct Net2 (src/dlrmtest.cpp:217-278)      dlrm_amd::Net2
 //   create_emb / save_emb / update_parameter    folded into emb (no mini-table is materialised:
@@ -159,6 +160,9 @@ public:
     int64_t pool_rows() const { return pool_rows_; }
     int tables() const { return T_; }
     int dim() const { return dim_; }
+    static constexpr bool sorts_ids = true;             // create_emb sorts a batch's ids (src/dlrmtest.cpp:62-63)
+    static constexpr int counter_stride = 6;
+    void restore(std::vector<int> &, int) {}            // pages of the batch are never dropped by its own reclaim
     void flush() { check(dlrm_cache_flush(h_, nullptr), "dlrm_cache_flush"); hip_check(hipDeviceSynchronize(), "sync"); }
     const float *store(int t) const { return static_cast<const float *>(stores_[t]); }
     int64_t error_flags() {
@@ -218,11 +222,165 @@ inline void reclaim_emb_cache(cache &c, std::ofstream *csv, double now) {
     }
 }
 
-// struct emb (src/dlrmtest.cpp:144-210): the EmbeddingBags of one batch.
-struct emb {
+// class cache2 (include/data2.h:219-287): the vector-granular policy -- rows are resident one by one, a table
+// lists the rows that were asked for (oldest first), evicted rows are repacked into new pages of the store.
+class cache2 {
+public:
+    // cache2(table_num, size, dimention) (include/data2.h:228) plus the sizes the reference takes from globals
+    // or leaves unbounded: listed rows per table (cache_size, src/dlrmtest2.cpp:53), rows of the HBM pool
+    // (listed rows + rows that come along with a page) and pages a table may write.
+    cache2(int table_num, int size, int dimention, int64_t cache_rows, int64_t num_slots, int64_t log_pages)
+        : cache_size((int)cache_rows), page_count(0), hot_page_count(0), T_(table_num), rows_(size), dim_(dimention) {
+        check_abi();
+        vector_page_offset = 4096 / (dimention * (int)sizeof(float));   // include/data2.h:161
+        write_buf = new write_buffer[table_num];
+        stores_.resize(table_num, nullptr);
+        std::vector<int64_t> rows(table_num, size);
+        const int64_t n_init = ((int64_t)size + vector_page_offset - 1) / vector_page_offset;
+        for (int t = 0; t < table_num; t++)
+            check(dlrm_host_alloc(&stores_[t], (size_t)(n_init + log_pages) * 4096), "dlrm_host_alloc");
+        dlrm_vcache_config cfg{};
+        cfg.num_tables = table_num; cfg.dim = dimention; cfg.rows_per_page = vector_page_offset;
+        cfg.evict_group = 8;   // nvm_dev_get_ws_opt() of the reference's device
+        cfg.table_rows = rows.data(); cfg.h_table_store = stores_.data();
+        cfg.log_pages_per_table = log_pages; cfg.num_slots = num_slots; cfg.cache_size = cache_rows; cfg.d_slot_pool = nullptr;
+        check(dlrm_vcache_create(&cfg, &h_), "dlrm_vcache_create");
+        void *pool = nullptr;
+        check(dlrm_vcache_storage(h_, &pool, &pool_rows_), "dlrm_vcache_storage");
+        pool_ = static_cast<float *>(pool);
+        ids_dev_.resize(table_num);
+        rows_dev_.resize(table_num);
+    }
+    ~cache2() {
+        (void)hipDeviceSynchronize();
+        dlrm_vcache_destroy(h_);
+        for (void *p : stores_) dlrm_host_free(p);
+        delete[] write_buf;
+    }
+    cache2(const cache2 &) = delete;
+
+    // embedding_table_init2::write(): uniform [0,1) tables in the backing store
+    void write(uint64_t seed = 0) {
+        for (int t = 0; t < T_; t++)
+            check(dlrm_table_init_uniform(stores_[t], DLRM_F32, (int64_t)rows_ * dim_, (seed << 20) + 7919ull * (t + 1), 0,
+                                          nullptr), "dlrm_table_init_uniform");
+        hip_check(hipDeviceSynchronize(), "sync");
+    }
+
+    // cache2::get_emb_vectors (include/data2.h:224): the device array holding, for every id (in the caller's
+    // order), its row inside the slot pool
+    const int *get_emb_vectors(std::vector<int> &vectors, int table_ID) {
+        const std::vector<int64_t> offs = one_table(table_ID, vectors.size());
+        ids_dev_[table_ID].upload(vectors);
+        rows_dev_[table_ID].resize(vectors.size());
+        check(dlrm_vcache_lookup(h_, ids_dev_[table_ID].p, DLRM_I32, offs.data(), rows_dev_[table_ID].p, nullptr),
+              "dlrm_vcache_lookup");
+        refresh();
+        return rows_dev_[table_ID].p;
+    }
+    // save_emb's side effect (src/dlrmtest2.cpp:169-177): rows of the batch that reclaim dropped are resident again
+    void restore(std::vector<int> &vectors, int table_ID) {
+        const std::vector<int64_t> offs = one_table(table_ID, vectors.size());
+        ids_dev_[table_ID].upload(vectors);
+        check(dlrm_vcache_restore(h_, ids_dev_[table_ID].p, DLRM_I32, offs.data(), nullptr, nullptr), "dlrm_vcache_restore");
+    }
+    // reclaim_emb_cache's loops (src/dlrmtest2.cpp:465-470) run inside the library
+    void reclaim() {
+        check(dlrm_vcache_set_cache_size(h_, cache_size, nullptr), "dlrm_vcache_set_cache_size");
+        check(dlrm_vcache_reclaim(h_, nullptr), "dlrm_vcache_reclaim");
+        refresh();
+    }
+    void Reclaim_vector_page(int) { throw std::runtime_error("use reclaim_emb_cache(cache2&)"); }
+
+    int get_pu() const { return 8; }
+    void read_page(int i) { reset_one(i, true); }     // include/data2.h:263-268
+    void write_page(int i) { reset_one(i, false); }   // include/data2.h:269-274
+    void dump_chunk_sector_stats(const std::string &) {}
+
+    float *pool() const { return pool_; }
+    int64_t pool_rows() const { return pool_rows_; }
+    int tables() const { return T_; }
+    int dim() const { return dim_; }
+    static constexpr bool sorts_ids = false;            // create_emb of dlrmtest2 keeps the request order (:63-67, :128)
+    static constexpr int counter_stride = DLRM_VCACHE_NUM_COUNTERS;
+    void flush() { hip_check(hipDeviceSynchronize(), "sync"); }   // rows are read back through read_rows
+    // current values of rows [0, n) of one table, wherever they live
+    std::vector<float> read_rows(int table, int n) {
+        std::vector<int> ids(n);
+        for (int i = 0; i < n; i++) ids[i] = i;
+        DeviceArray<int> d_ids; d_ids.upload(ids);
+        DeviceArray<float> out((size_t)n * dim_);
+        const std::vector<int64_t> offs = one_table(table, (size_t)n);
+        check(dlrm_vcache_read_rows(h_, d_ids.p, DLRM_I32, offs.data(), out.p, nullptr), "dlrm_vcache_read_rows");
+        return out.download((size_t)n * dim_);
+    }
+    int64_t error_flags() {
+        dlrm_vcache_state_t st;
+        check(dlrm_vcache_state(h_, &st, nullptr), "dlrm_vcache_state");
+        return st.error_flags;
+    }
+    // cumulative per-table counters, DLRM_VCACHE_NUM_COUNTERS per table (the first six as in class cache)
+    const std::vector<int64_t> &counters() {
+        refresh();
+        return last_;
+    }
+
+    // public state the reference driver reads or sets (include/data2.h:256-258, :281)
+    int cache_size;
+    int page_count;
+    int hot_page_count;      // set by the driver (src/dlrmtest2.cpp:539); the classification it feeds is inert as shipped
+    int vector_page_offset;
+    write_buffer *write_buf;
+
+private:
+    std::vector<int64_t> one_table(int table_ID, size_t n) const {
+        std::vector<int64_t> offs(T_ + 1, 0);
+        for (int t = table_ID + 1; t <= T_; t++) offs[t] = (int64_t)n;
+        return offs;
+    }
+    void refresh() {
+        dlrm_vcache_state_t st;
+        check(dlrm_vcache_state(h_, &st, nullptr), "dlrm_vcache_state");
+        page_count = (int)st.page_count;
+        std::vector<int64_t> c((size_t)T_ * counter_stride);
+        check(dlrm_vcache_counters(h_, c.data(), 0, nullptr), "dlrm_vcache_counters");
+        for (int t = 0; t < T_; t++) {
+            write_buf[t].read_page_count = (int)(c[t * counter_stride + 0] - read_base_[t]);
+            write_buf[t].write_page_count = (int)(c[t * counter_stride + 1] - write_base_[t]);
+        }
+        last_ = c;
+    }
+    void reset_one(int i, bool read) {
+        if (last_.empty()) refresh();
+        if (read) { read_base_[i] = last_[i * counter_stride + 0]; write_buf[i].read_page_count = 0; }
+        else { write_base_[i] = last_[i * counter_stride + 1]; write_buf[i].write_page_count = 0; }
+    }
+
+    dlrm_vcache *h_ = nullptr;
+    int T_, rows_, dim_;
+    std::vector<void *> stores_;
+    float *pool_ = nullptr;
+    int64_t pool_rows_ = 0;
+    std::vector<DeviceArray<int>> ids_dev_, rows_dev_;
+    std::vector<int64_t> last_;
+    std::vector<int64_t> read_base_ = std::vector<int64_t>(64, 0), write_base_ = std::vector<int64_t>(64, 0);
+};
+
+// reclaim_emb_cache (src/dlrmtest2.cpp:462-481)
+inline void reclaim_emb_cache(cache2 &c, std::ofstream *csv, double now) {
+    c.reclaim();
+    for (int i = 0; i < c.tables(); i++) {
+        if (csv) *csv << now << ";" << i / c.get_pu() << ";" << i % c.get_pu() << ";" << ";" << c.write_buf[i].write_page_count << "\n";
+        c.write_page(i);
+    }
+}
+
+// struct emb (src/dlrmtest.cpp:144-210; src/dlrmtest2.cpp:215-290): the EmbeddingBags of one batch, over either cache.
+template <class Cache>
+struct emb_t {
     // x: the batch as the reference lays it out, [batch][dense_feature + T*lookup_num] floats with the
     // ids float-encoded after the dense features (src/dlrmtest.cpp:150, :309-313)
-    emb(const float *x, int batch, int dense_feature, int lookup_num, cache &c, std::ofstream *csv, double now)
+    emb_t(const float *x, int batch, int dense_feature, int lookup_num, Cache &c, std::ofstream *csv, double now)
         : c_(c), B_(batch), L_(lookup_num) {
         const int T = c.tables(), row = dense_feature + T * lookup_num;
         std::vector<int> all_rows((size_t)T * batch * lookup_num);
@@ -231,8 +389,9 @@ struct emb {
             std::vector<int> ids((size_t)batch * lookup_num);
             for (int b = 0; b < batch; b++)
                 for (int l = 0; l < lookup_num; l++) ids[(size_t)b * lookup_num + l] = (int)x[(size_t)b * row + dense_feature + t * lookup_num + l];
-            std::sort(ids.begin(), ids.end());
+            if (Cache::sorts_ids) std::sort(ids.begin(), ids.end());
             const int *d_rows = c.get_emb_vectors(ids, t);
+            ids_.push_back(ids);
             hip_check(hipMemcpy(all_rows.data() + (size_t)t * batch * lookup_num, d_rows, sizeof(int) * ids.size(),
                                 hipMemcpyDeviceToHost), "rows D2H");
         }
@@ -287,11 +446,19 @@ struct emb {
         check(dlrm_embbag_backward_update(&e, d_grad, ld, &o, ws.p, ws.n, nullptr), "dlrm_embbag_backward_update");
     }
 
-    cache &c_;
+    // the batch's rows that the reclaim after the lookups has dropped come back (cache2 only)
+    void restore() {
+        for (int t = 0; t < c_.tables(); t++) c_.restore(ids_[t], t);
+    }
+
+    Cache &c_;
     int B_, L_;
+    std::vector<std::vector<int>> ids_;
     DeviceArray<int> rows_, off_;
     DeviceArray<float> pooled_;
 };
+using emb = emb_t<cache>;
+using emb2 = emb_t<cache2>;
 
 // struct Net2 (src/dlrmtest.cpp:217-278): bottom dense->128->32, concat with the pooled tables,
 // (32 + T*D)->32->1, ReLU after every layer.

@@ -11,6 +11,9 @@
 //   --trace FILE     per batch and table: lookups that hit / missed, pages read / written / evicted / resident
 //                    ('Time';'Epoch';'Batch';'Table';'Hit';'Miss';'Read';'Write';'Evicted';'Resident'; deltas per batch)
 //   --canonical      train every table (duplicates accumulate) and the MLP instead of the loop as shipped
+//   --policy vec     the cache of src/dlrmtest2.cpp (class cache2): rows cached one by one, cache_mult * lookups *
+//                    batch_size listed rows per table (:53), evicted rows repacked into new pages; ids are not sorted.
+//                    --slots N (rows of the HBM pool) and --log-pages N (pages a table may write) size it
 //   --dump-table0 F  write table 0 (float32 [rows][dim]) after training, for parity checks
 //
 // As shipped (default) the loop reproduces what the reference executes, not what it
@@ -21,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <memory>
 
 #include "dlrm_adapter.hpp"
 
@@ -90,12 +94,51 @@ static void make_input(const Model &m, int N, Input &in) {
     }
 }
 
+struct Options {
+    Model m;
+    int data_size = 800, batch_size = 60, c = 6;   // src/dlrmtest.cpp:45-47
+    std::string input, csv_path, dump0, trace_path;
+    bool canonical = false, vec = false;
+    int64_t slots = 0, log_pages = 0;
+};
+
+static cache *make_cache(const Options &o, cache *) {
+    const Model &m = o.m;
+    const int cache_size = o.c * m.T * m.L * o.batch_size;   // src/dlrmtest.cpp:436
+    return new cache(m.T, m.rows, m.D, cache_size, (int64_t)m.T * m.L * o.batch_size + 64);
+}
+static cache2 *make_cache(const Options &o, cache2 *) {
+    const Model &m = o.m;
+    const int64_t cache_rows = (int64_t)o.c * m.L * o.batch_size;   // src/dlrmtest2.cpp:509
+    const int vpo = 4096 / (m.D * 4);
+    // every lookup can bring a whole page; the written region takes what all batches can evict
+    const int64_t per_batch = (int64_t)m.L * o.batch_size;
+    const int64_t batches = (int64_t)m.epochs * ((o.data_size + o.batch_size - 1) / o.batch_size);
+    const int64_t slots = o.slots ? o.slots : std::min<int64_t>((int64_t)m.T * m.rows, (int64_t)m.T * per_batch * vpo * batches);
+    const int64_t log_pages = o.log_pages ? o.log_pages : (per_batch * batches + vpo - 1) / vpo + 16;
+    return new cache2(m.T, m.rows, m.D, cache_rows, slots, log_pages);
+}
+static void freeze_capacity(cache &c, int b, int epoch, int mult) {
+    if (b + 1 == mult && epoch == 1) c.cache_size = c.page_count;   // src/dlrmtest.cpp:496-498
+}
+static void freeze_capacity(cache2 &, int, int, int) {}               // dlrmtest2 keeps its capacity
+static std::vector<float> table0(cache &c, const Model &m) {
+    c.flush();
+    const float *t0 = c.store(0);
+    return std::vector<float>(t0, t0 + (size_t)m.rows * m.D);
+}
+static std::vector<float> table0(cache2 &c, const Model &m) { return c.read_rows(0, m.rows); }
+
+template <class Cache>
+static int train(Options o);
+
 int main(int argc, char *argv[]) {
     try {
-        Model m;
-        int data_size = 800, batch_size = 60, c = 6;   // src/dlrmtest.cpp:45-47
-        std::string input, csv_path, dump0, trace_path;
-        bool canonical = false;
+        Options o;
+        Model &m = o.m;
+        int &data_size = o.data_size, &batch_size = o.batch_size, &c = o.c;
+        std::string &input = o.input, &csv_path = o.csv_path, &dump0 = o.dump0, &trace_path = o.trace_path;
+        bool &canonical = o.canonical;
         std::vector<std::string> pos;
         for (int i = 1; i < argc; i++) {
             std::string a = argv[i];
@@ -111,13 +154,30 @@ int main(int argc, char *argv[]) {
             else if (a == "--trace") trace_path = next();
             else if (a == "--canonical") canonical = true;
             else if (a == "--dump-table0") dump0 = next();
+            else if (a == "--policy") { const std::string v = next(); if (v != "vec" && v != "page") throw std::runtime_error("--policy page|vec"); o.vec = v == "vec"; }
+            else if (a == "--slots") o.slots = std::stoll(next());
+            else if (a == "--log-pages") o.log_pages = std::stoll(next());
             else pos.push_back(a);
         }
         if (pos.size() == 3) { data_size = std::stoi(pos[0]); batch_size = std::stoi(pos[1]); c = std::stoi(pos[2]); }
         else if (!pos.empty()) throw std::runtime_error("usage: dlrmtest_amd data_size batch_size cache_mult [options]");
-        int cache_size = c * m.T * m.L * batch_size;   // :436
+        return o.vec ? train<cache2>(o) : train<cache>(o);
+    } catch (const std::exception &e) {
+        std::cerr << "dlrmtest_amd: " << e.what() << std::endl;
+        return 1;
+    }
+}
 
-        std::string name = csv_path.empty() ? "LRU_BASE_AMD_C" + std::to_string(c) + "_B" + std::to_string(batch_size) + "_D" +
+template <class Cache>
+static int train(Options o) {
+    {
+        Model &m = o.m;
+        int data_size = o.data_size, batch_size = o.batch_size, c = o.c;
+        const std::string &input = o.input, &csv_path = o.csv_path, &dump0 = o.dump0, &trace_path = o.trace_path;
+        const bool canonical = o.canonical;
+        constexpr int CS = Cache::counter_stride;
+
+        std::string name = csv_path.empty() ? std::string(o.vec ? "LRU_AMD_C" : "LRU_BASE_AMD_C") + std::to_string(c) + "_B" + std::to_string(batch_size) + "_D" +
                                                   std::to_string(data_size) + ".csv" : csv_path;
         std::ofstream myfile(name);
         myfile << "'Time';'Channel';'PU';'Read';'Write'" << std::endl;   // :448
@@ -137,7 +197,8 @@ int main(int argc, char *argv[]) {
 
         Net2 net2(m.dense, m.T, m.D);
         for (int l = 0; l < 4; l++) net2.set_layer(l, in.W[l], in.b[l]);
-        cache emb_cache(m.T, m.rows, m.D, cache_size, (int64_t)m.T * m.L * batch_size + 64);
+        std::unique_ptr<Cache> cache_holder(make_cache(o, (Cache *)nullptr));
+        Cache &emb_cache = *cache_holder;
         emb_cache.write();
 
         const int row = m.dense + m.T * m.L, cat = net2.cat, bb = batch_size;
@@ -155,9 +216,19 @@ int main(int argc, char *argv[]) {
                 batch_size = std::min(bb, data_size - s0);   // last partial batch (:479-482)
                 const int B = batch_size;
                 const float *xb = in.data.data() + (size_t)s0 * row;
-                emb embedding(xb, B, m.dense, m.L, emb_cache, &myfile, now());
-                reclaim_emb_cache(emb_cache, &myfile, now());
-                if (b + 1 == c && epoch == 1) emb_cache.cache_size = emb_cache.page_count;   // :496-498
+                emb_t<Cache> embedding(xb, B, m.dense, m.L, emb_cache, &myfile, now());
+                // The page cache reclaims here, like the reference (:494): the pages of the batch are its most
+                // recent ones and stay.  The vector cache lists rows by their FIRST request, so a reclaim may drop
+                // rows of this very batch (the reference works on a copy and loses their update,
+                // src/dlrmtest2.cpp:558-559, :595): it runs after the rows are updated instead -- the cache sees
+                // the same calls in the same order either way.
+                auto reclaim_now = [&]() {
+                    reclaim_emb_cache(emb_cache, &myfile, now());
+                    freeze_capacity(emb_cache, b, epoch, c);
+                    embedding.restore();
+                };
+                if (Cache::sorts_ids) reclaim_now();
+                auto write_trace = [&]() {
                 if (trace.is_open()) {
                     const std::vector<int64_t> cur = emb_cache.counters();
                     if (trace_prev.empty()) trace_prev.assign(cur.size(), 0);
@@ -165,11 +236,13 @@ int main(int argc, char *argv[]) {
                     for (int t = 0; t < m.T; t++) {
                         trace << tnow << ";" << epoch << ";" << b << ";" << t;
                         static const int order[5] = {2, 3, 0, 1, 4};   // hit, miss, read, write, evicted
-                        for (int k : order) trace << ";" << cur[t * 6 + k] - trace_prev[t * 6 + k];
-                        trace << ";" << cur[t * 6 + 5] << "\n";
+                        for (int k : order) trace << ";" << cur[t * CS + k] - trace_prev[t * CS + k];
+                        trace << ";" << cur[t * CS + 5] << "\n";
                     }
                     trace_prev = cur;
                 }
+                };
+                if (Cache::sorts_ids) write_trace();
 
                 std::vector<float> xd((size_t)B * m.dense);
                 for (int i = 0; i < B; i++) std::memcpy(&xd[(size_t)i * m.dense], xb + (size_t)i * row, sizeof(float) * m.dense);
@@ -227,6 +300,7 @@ int main(int argc, char *argv[]) {
                         check(dlrm_sgd_step(net2.b[l].p, db[l].p, N_[l], 0.01f, nullptr), "sgd b");
                     }
                 }
+                if (!Cache::sorts_ids) { reclaim_now(); write_trace(); }
                 const float lv = loss.download(1)[0];
                 std::cout << "{\"epoch\": " << epoch << ", \"batch\": " << b << ", \"batch_size\": " << B << ", \"loss\": " << lv
                           << ", \"page_count\": " << emb_cache.page_count << ", \"cache_size\": " << emb_cache.cache_size << "}"
@@ -234,21 +308,17 @@ int main(int argc, char *argv[]) {
             }
         }
         const int64_t flags = emb_cache.error_flags();
-        emb_cache.flush();
         // checksum of table 0 after training (for parity checks) and timing like the reference (:548-554)
         double sum0 = 0.0;
-        const float *t0 = emb_cache.store(0);
-        for (size_t i = 0; i < (size_t)m.rows * m.D; i++) sum0 += t0[i];
+        const std::vector<float> t0 = table0(emb_cache, m);
+        for (size_t i = 0; i < t0.size(); i++) sum0 += t0[i];
         if (!dump0.empty()) {
             FILE *f = fopen(dump0.c_str(), "wb");
-            if (!f || fwrite(t0, 4, (size_t)m.rows * m.D, f) != (size_t)m.rows * m.D) throw std::runtime_error("cannot write " + dump0);
+            if (!f || fwrite(t0.data(), 4, t0.size(), f) != t0.size()) throw std::runtime_error("cannot write " + dump0);
             fclose(f);
         }
         std::cout << "{\"table0_sum\": " << sum0 << ", \"error_flags\": " << flags << ", \"training_time_s\": " << now() << "}" << std::endl;
         emb_cache.dump_chunk_sector_stats("chunk_statistics");
         return 0;
-    } catch (const std::exception &e) {
-        std::cerr << "dlrmtest_amd: " << e.what() << std::endl;
-        return 1;
     }
 }

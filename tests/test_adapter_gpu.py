@@ -120,3 +120,76 @@ def test_driver_rmc1_matches_reference_csv(tmp_path):
     assert [t["hit"] + t["miss"] for t in tr] == [T * L * n for _ in range(len(tr) // len(sizes)) for n in sizes]
     assert lines[-1]["error_flags"] == 0
     assert all(np.isfinite(l["loss"]) for l in lines if "loss" in l)
+
+
+VEC_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_lru_vec_trace.json")))
+
+
+def test_driver_vector_policy_matches_reference_dlrmtest2_csv(tmp_path):
+    """--policy vec on the reference's dlrmtest2 run (25 tables x 800000 rows x 32, 20 lookups): the CSV the
+    driver writes carries, per batch and table, the page reads and writes of the reference's own CSV."""
+    cfg = VEC_GOLD["vec_t25_d32_l20"]
+    T, D, L = cfg["tables"], cfg["dim"], cfg["lookups"]
+    B, N, c, rows = cfg["batch"], cfg["data_size"], cfg["cache_mult"], cfg["rows_per_table"]
+    x, ids, y = reference_dataset(T, L, B, N, rows)
+    rng = np.random.default_rng(0)
+    cat = 32 + T * D
+    W = [(rng.standard_normal((128, 256)) / 16).astype(np.float32), (rng.standard_normal((32, 128)) / 11).astype(np.float32),
+         (rng.standard_normal((32, cat)) / 32).astype(np.float32), (rng.standard_normal((1, 32)) / 5).astype(np.float32)]
+    b = [np.abs(rng.standard_normal(n)).astype(np.float32) * 0.1 for n in (128, 32, 32, 1)]
+    inp, csv = tmp_path / "in.bin", tmp_path / "out.csv"
+    write_input(inp, np.concatenate([x, ids.astype(np.float32)], axis=1), y.reshape(-1), W, b, T, D, rows, L, 256)
+    lines = run_driver([N, B, c, "--policy", "vec", "--tables", T, "--dim", D, "--rows", rows, "--lookups", L,
+                        "--input", inp, "--csv", csv, "--slots", 4_500_000, "--log-pages", 512], tmp_path)
+    got = [{"read": r, "write": w} for r, w in parse_csv(csv, T)]
+    assert got == cfg["batches"]
+    assert lines[-1]["error_flags"] == 0
+    assert all(np.isfinite(l["loss"]) for l in lines if "loss" in l)
+
+
+def test_driver_vector_policy_small(oracle, tmp_path):
+    """Small model, --canonical (every table trained) under --policy vec with a list short enough to evict:
+    the CSV equals the oracle's vector cache fed with the same calls, rows that were never asked for keep
+    their initial value wherever the cache has moved them, the asked ones train."""
+    T, D, rows, L, dense, N, B, c, epochs = 3, 32, 4000, 40, 16, 60, 10, 1, 2
+    rng = np.random.default_rng(2)
+    ids = rng.integers(0, rows, size=(N, T * L))
+    x = rng.standard_normal((N, dense)).astype(np.float32)
+    target = rng.standard_normal(N).astype(np.float32)
+    cat = 32 + T * D
+    W = [(rng.standard_normal((128, dense)) / 4).astype(np.float32), (rng.standard_normal((32, 128)) / 11).astype(np.float32),
+         (rng.standard_normal((32, cat)) / 12).astype(np.float32), (rng.standard_normal((1, 32)) / 5).astype(np.float32)]
+    b = [np.abs(rng.standard_normal(n)).astype(np.float32) * 0.1 for n in (128, 32, 32, 1)]
+    inp = tmp_path / "in.bin"
+    write_input(inp, np.concatenate([x, ids.astype(np.float32)], axis=1), target, W, b, T, D, rows, L, dense)
+    common = [N, B, c, "--tables", T, "--dim", D, "--rows", rows, "--lookups", L, "--dense", dense, "--epochs", epochs,
+              "--input", inp, "--canonical"]
+    vec = run_driver(common + ["--policy", "vec", "--csv", tmp_path / "v.csv", "--dump-table0", tmp_path / "v0.bin"], tmp_path)
+    assert vec[-1]["error_flags"] == 0
+    lv = [l["loss"] for l in vec if "loss" in l]
+    assert len(lv) == epochs * 6
+    v0 = np.fromfile(tmp_path / "v0.bin", dtype=np.float32)
+    init = oracle.table_init_uniform(rows * D, 7919)
+    assert v0.shape == init.shape
+    assert not np.array_equal(v0, init) and np.all(np.isfinite(v0)) and np.all(np.isfinite(lv))
+    # rows the run never asked for keep their initial value, wherever the cache has moved them
+    asked = np.zeros(rows, bool)
+    asked[ids[:, :L].reshape(-1)] = True
+    assert np.array_equal(v0.reshape(rows, D)[~asked], init.reshape(rows, D)[~asked])
+    assert np.any(v0.reshape(rows, D)[asked] != init.reshape(rows, D)[asked])
+    # cache traffic against the oracle's vector cache (c * L * B = 400 listed rows per table: evictions happen)
+    vc = oracle.VectorCache(T, rows, D, c * L * B)
+    ref = []
+    for epoch in range(epochs):
+        for s, bs in reference_batches(N, B):
+            req = [ids[s:s + bs, t * L:(t + 1) * L].reshape(-1) for t in range(T)]
+            for t in range(T):
+                vc.get(t, req[t])
+            reads = vc.counters("read", reset=True)
+            vc.reclaim()
+            writes = vc.counters("write", reset=True)
+            for t in range(T):
+                vc.save(t, req[t])
+            ref.append((reads.tolist(), writes.tolist()))
+    assert parse_csv(tmp_path / "v.csv", T) == ref
+    assert sum(sum(w) for _, w in ref) > 0
