@@ -158,17 +158,19 @@ def test_errors(oracle):
         vc.close()
 
 
-def test_replays_reference_dlrmtest2_run(oracle):
-    """The reference's own run (25 tables x 800000 rows x 32, 20 lookups, batch 40, 10 batches): per batch and
-    table the pages read and written that its CSV records."""
+@pytest.mark.parametrize("name,slots,log_pages", [("vec_t25_d32_l20", 4_500_000, 512),
+                                                  ("vec_t32_d64_l120", 10_000_000, 4096)])
+def test_replays_reference_dlrmtest2_run(oracle, name, slots, log_pages):
+    """The reference's own runs (25 tables x 800000 rows x 32 with 20 lookups; 32 x 500000 x 64 with 120
+    lookups; batch 40, 10 batches): per batch and table the pages read and written that its CSVs record."""
     from dlrm_amd.vcache import VectorCache
     from tests.test_oracle_veccache_csv import run_trace
-    cfg = GOLD["vec_t25_d32_l20"]
+    cfg = GOLD[name]
 
     class Replay:
         def __init__(self, T, rows, D, cache_size):
             self.T = T
-            self.vc = VectorCache([rows] * T, D, cache_size, num_slots=4_500_000, log_pages_per_table=512)
+            self.vc = VectorCache([rows] * T, D, cache_size, num_slots=slots, log_pages_per_table=log_pages)
 
         def _one(self, t, ids):
             d = torch.from_numpy(np.ascontiguousarray(ids)).cuda()
