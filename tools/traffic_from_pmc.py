@@ -24,9 +24,9 @@ RULES = [
     ("gemm_f32_kernel<false, false>", "linear_backward_weight", True),
     ("reduce_slabs_kernel", "linear_backward_weight", False),
     ("embbag_fwd", "embbag_forward", True),
-    ("expand_pairs_kernel", "embbag_backward_update", True),
-    ("rocprim", "embbag_backward_update", False),
-    ("sparse_update_kernel", "embbag_backward_update", False),
+    ("expand_pairs_kernel", "embbag_backward_prepare", True),    # ids only: pairs + sort, beside the forward pass
+    ("rocprim", "embbag_backward_prepare", False),
+    ("sparse_update_kernel", "embbag_backward_update", True),
     ("combine_runs_kernel", "embbag_backward_update", False),
     ("interact_dot_fwd", "interact_dot_forward", True),
     ("interact_dot_bwd", "interact_dot_backward", True),
