@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--cache-fraction", type=float, default=0.0,
                     help="tables in pinned host DRAM behind an HBM cache of this fraction of their pages (0 = tables in HBM)")
     ap.add_argument("--cache-rows-per-page", type=int, default=1)
+    ap.add_argument("--cache-policy", default="lru", choices=["lru", "vec"],
+                    help="lru: page / row LRU cache; vec: rows listed oldest request first, evicted rows repacked into new "
+                         "pages (the reference's second policy)")
     ap.add_argument("--no-prefetch", action="store_true", help="cached mode: look ids up inside the step")
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
     ap.add_argument("--eager", action="store_true",
@@ -214,7 +217,8 @@ def main():
     cached = args.cache_fraction > 0
     model = DLRM(cfg, B, device=dev, rank=rank, world=world, seed=0, process_group=pg, plan=plan,
                  cache_fraction=args.cache_fraction if cached else None,
-                 cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager,
+                 cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager, cache_policy=args.cache_policy,
+                 cache_log_pages=((args.steps + args.warmup + 2) * Bg * cfg.lookups) // 8 + 64,
                  overlap=False if args.no_overlap else (True if args.overlap else None), presort=False if args.no_presort else None)
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
@@ -241,7 +245,7 @@ def main():
         dense, idx, off, labels, (uniq, uniq_rw) = batches[i % n_batches]
         model_ref["unique_rows"], model_ref["unique_rows_rw"] = uniq, uniq_rw
         model.load_batch(dense, labels)
-        if cached and not args.no_prefetch:
+        if cached and not args.no_prefetch and args.cache_policy == "lru":
             out = model.train_step(idx, off, next_indices=batches[(i + 1) % n_batches][1])
         else:
             out = model.train_step(idx, off)
@@ -346,13 +350,15 @@ def main():
         c1, st = model.cache.counters(), model.cache.state()
         hit = int((c1["hit"] - cache_c0["hit"]).sum())
         miss = int((c1["miss"] - cache_c0["miss"]).sum())
-        page_bytes = args.cache_rows_per_page * cfg.dim * 4
-        cache_info = {"fraction": args.cache_fraction, "rows_per_page": args.cache_rows_per_page,
-                      "prefetch": not args.no_prefetch, "hit_rate_lookups": hit / max(hit + miss, 1),
+        vec = args.cache_policy == "vec"
+        page_bytes = 4096 if vec else args.cache_rows_per_page * cfg.dim * 4
+        cache_info = {"policy": args.cache_policy, "fraction": args.cache_fraction,
+                      "rows_per_page": 4096 // (cfg.dim * 4) if vec else args.cache_rows_per_page,
+                      "prefetch": not args.no_prefetch and not vec, "hit_rate_lookups": hit / max(hit + miss, 1),
                       "pages_read_per_step": int(c1["read"].sum()) / args.steps,
                       "pages_written_back_per_step": int(c1["write"].sum()) / args.steps,
                       "h2d_GBps": int(c1["read"].sum()) * page_bytes / dt / 1e9,
-                      "cache_GB": st.cache_size * page_bytes / 1e9,
+                      "cache_GB": (model.cache.num_slots * cfg.dim * 4 if vec else st.cache_size * page_bytes) / 1e9,
                       "table_GB": sum(cfg.table_rows[t] for t in model.local_table_ids) * cfg.dim * 4 / 1e9,
                       "error_flags": int(st.error_flags)}
 

@@ -175,7 +175,8 @@ class MLPStack:
 class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
                  seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
-                 cache_rows_per_page=1, replay=False, presort=None):
+                 cache_rows_per_page=1, replay=False, presort=None, cache_policy="lru",
+                 cache_log_pages=4096):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
@@ -184,7 +185,12 @@ class DLRM:
         an HBM cache (dlrm_amd.cache.EmbeddingCache, the reference's `class cache`); every step looks
         its ids up (misses are filled over the host link), pools and updates rows inside the cache's
         slot pool and reclaims down to the capacity.  `train_step(..., next_indices=...)` looks the next
-        batch up on a second stream while this one computes."""
+        batch up on a second stream while this one computes.
+        cache_policy: "lru" (pages or rows, least recently used: `class cache`) or "vec" (the reference's
+        `class cache2`, dlrm_amd.vcache.VectorCache: rows cached one by one, every table lists up to
+        cache_fraction x (rows of the largest table) rows oldest request first, evicted rows are repacked
+        into new pages of the store; float32 rows, 4096-byte pages; cache_log_pages = pages a table may
+        write over the run)."""
         _capi.lib()  # fail loudly if the HIP library is missing
         self.cfg, self.B, self.rank, self.world, self.pg = cfg, batch, rank, world, process_group
         self.Bg = batch * world
@@ -220,17 +226,33 @@ class DLRM:
         if cache_fraction is not None:
             if self.rw_tables or cfg.emb_optimizer != "sgd":
                 raise ValueError("the cached mode supports whole tables and the SGD row update")
-            from .cache import EmbeddingCache
             esz = 2 if cfg.row_dtype == "bf16" else 4
             rpp = cache_rows_per_page
-            pages = sum((r + rpp - 1) // rpp for r in rows)
-            cache_pages = max(int(pages * cache_fraction), 1)
-            # a lookup can bring in one page per id of the global batch on top of the capacity
-            headroom = min(pages, self.Tl * self.Bg * cfg.lookups)
-            self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
-                                        row_dtype=wdtype, device=dev)
-            if init_tables:
-                self.cache.write(seed, table_ids=self.local_table_ids)
+            self.cache_policy = cache_policy
+            if cache_policy == "vec":
+                from .vcache import VectorCache
+                if wdtype != torch.float32:
+                    raise ValueError("the vector-granular cache holds float32 rows")
+                rpp = 4096 // (D * 4)
+                per_step = self.Bg * cfg.lookups                      # new rows a table can list per step
+                cap = max(int(max(rows) * cache_fraction), 8 * rpp)
+                # listed rows plus the rows that come along with the pages of one step; evictions of all steps
+                slots = sum(min(r, (cap + 2 * per_step) * rpp) for r in rows)
+                self.cache = VectorCache(rows, D, cap, slots, log_pages_per_table=cache_log_pages, device=dev)
+                if init_tables:
+                    self.cache.write_tables(seed, self.local_table_ids)
+            elif cache_policy == "lru":
+                from .cache import EmbeddingCache
+                pages = sum((r + rpp - 1) // rpp for r in rows)
+                cache_pages = max(int(pages * cache_fraction), 1)
+                # a lookup can bring in one page per id of the global batch on top of the capacity
+                headroom = min(pages, self.Tl * self.Bg * cfg.lookups)
+                self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
+                                            row_dtype=wdtype, device=dev)
+                if init_tables:
+                    self.cache.write(seed, table_ids=self.local_table_ids)
+            else:
+                raise ValueError("cache_policy must be 'lru' or 'vec'")
             self.weight = self.cache.pool
             self.table_row_offsets = None          # ids are translated to rows of the shared slot pool
             self._rows = None
@@ -642,7 +664,14 @@ class DLRM:
         With `replay` the step's operators are recorded into a dlrm_plan on the first call and
         replayed afterwards (same kernels, same order, one C call per stretch between collectives)."""
         pipelined = False
-        if self.cache is not None:
+        ids = indices
+        if self.cache is not None and self.cache_policy == "vec":
+            # cache2's order of calls: lookups of every table, (the step), reclaim, save_emb's restore
+            if next_indices is not None:
+                raise ValueError("the vector-granular cache does not look ahead")
+            self._vec_pos = self._table_pos(indices, table_pos)
+            indices = self.cache.get_emb_vectors(indices, self._vec_pos)
+        elif self.cache is not None:
             if self._rows is not None and self._rows[0] is indices:
                 _, rows, ev = self._rows
                 torch.cuda.current_stream().wait_event(ev)
@@ -669,7 +698,10 @@ class DLRM:
                     self._plan.enable_timing(self.plan_timing_runs)
             self._plan.set_batch(indices, offsets)
             self._run_items(self._plan_items, self._plan)
-        if self.cache is not None:
+        if self.cache is not None and self.cache_policy == "vec":
+            self.cache.reclaim()
+            self.cache.restore(ids, self._vec_pos)
+        elif self.cache is not None:
             if pipelined:
                 self._pipeline_next(next_indices, next_table_pos)
             else:

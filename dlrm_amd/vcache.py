@@ -102,9 +102,14 @@ class VectorCache:
 
     def write(self, seed=0):
         """embedding_table_init2::write(): every table uniform [0,1)."""
+        self.write_tables(seed, range(self.T))
+
+    def write_tables(self, seed, table_ids):
+        """table_ids: the global id of each table (its random stream is keyed by it)."""
         for t, p in enumerate(self._ptrs):
             n = self.table_rows[t] * self.dim
-            check(self.L.dlrm_table_init_uniform(p, _capi.F32, C.c_int64(n), C.c_uint64((seed << 20) + 7919 * (t + 1)),
+            check(self.L.dlrm_table_init_uniform(p, _capi.F32, C.c_int64(n),
+                                                 C.c_uint64((seed << 20) + 7919 * (table_ids[t] + 1)),
                                                  C.c_int64(0), self._stream()))
         torch.cuda.synchronize()
 

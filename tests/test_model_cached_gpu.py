@@ -62,3 +62,48 @@ def test_cached_training_matches_oracle(oracle, rows_per_page, prefetch, kind):
     for t in range(T):
         assert rel_err(np.asarray(m.cache.store[t]), tables[t]) <= 1e-5
     m.cache.close()
+
+
+@pytest.mark.parametrize("replay", [False, True], ids=["eager", "replay"])
+@pytest.mark.parametrize("kind", ["dot", "cat"])
+def test_training_through_the_vector_cache_matches_oracle(oracle, kind, replay):
+    """DLRM(cache_policy="vec"): the tables sit behind the vector-granular cache (rows listed oldest request
+    first, evicted rows repacked into new pages).  Losses and predictions must match the oracle's step on whole
+    tables, and at the end every row must read back with the oracle's value wherever the cache keeps it."""
+    from dlrm_amd.model import DLRM, DLRMConfig
+    if kind == "dot":
+        cfg = DLRMConfig(table_rows=[6000, 500, 9000, 640], dim=16, dense_in=13, bottom=[32, 16], top=[24, 1], lr=0.05,
+                         lookups=2)
+    else:
+        cfg = DLRMConfig(table_rows=[4000, 3000, 7000], dim=32, dense_in=6, bottom=[16, 32], top=[12, 1], interaction="cat",
+                         loss="mse", final_relu=True, pooling="mean", lookups=3, lr=0.02)
+    B = 128
+    vpo = 4096 // (4 * cfg.dim)
+    frac = 8 * vpo / max(cfg.table_rows) * 1.05          # lists barely longer than one write buffer: evictions from step 2 on
+    m = DLRM(cfg, B, seed=5, cache_fraction=frac, cache_policy="vec", replay=replay)
+    if kind == "cat":
+        for b in m.bottom.b + m.top.b:
+            b.abs_()
+    T = cfg.num_tables
+    tables = [oracle.table_init_uniform(r * cfg.dim, (5 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+              for t, r in enumerate(cfg.table_rows)]
+    Ws = [w.cpu().numpy().copy() for w in m.bottom.W + m.top.W]
+    bs = [b.cpu().numpy().copy() for b in m.bottom.b + m.top.b]
+    rng = np.random.default_rng(33)
+    for s in range(8):
+        dense, idx, off, labels = make_batch(rng, cfg, B)
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        loss = m.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(off.astype(np.int32)).cuda())
+        torch.cuda.synchronize()
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                               cfg.lr)
+        assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        assert m.cache.state().error_flags == 0 and int(m.err_flag.item()) == 0
+    cnt = m.cache.counters()
+    assert cnt["miss"].sum() > 0 and cnt["hit"].sum() > 0 and cnt["evicted"].sum() > 0 and cnt["write"].sum() > 0
+    for t in range(T):
+        ids = torch.arange(cfg.table_rows[t], dtype=torch.int32, device="cuda")
+        offs = [0] * (t + 1) + [cfg.table_rows[t]] * (T - t)
+        assert rel_err(m.cache.read_rows(ids, offs).cpu().numpy(), tables[t]) <= 1e-5
+    m.cache.close()
