@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "skinny.h"
 
 namespace dlrm {
 
@@ -775,6 +776,13 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
     DLRM_REQUIRE(l->d_x && l->d_w && l->d_y, "NULL operand");
     DLRM_REQUIRE(l->x_ld >= l->K && l->w_ld >= l->K && l->y_ld >= l->N, "leading dimension too small");
+    // the two shapes that are no matrix product: a few input columns, or one output column
+    if (skinny_k_forward_ok(l->N, l->K))
+        return skinny_k_forward(l->d_x, l->x_ld, l->d_w, l->w_ld, l->d_bias, l->d_y, l->y_ld, (int)l->M, l->N, l->K,
+                                l->act == DLRM_ACT_RELU, as_stream(stream));
+    if (l->N == 1 && gemv_ok(l->d_x, l->x_ld, l->d_w, l->K))
+        return gemv_forward(l->d_x, l->x_ld, l->d_w, l->d_bias, l->d_y, l->y_ld, (int)l->M, l->K, l->act == DLRM_ACT_RELU,
+                            as_stream(stream));
     GemmParams p{};
     p.A = l->d_x; p.lda = l->x_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_y; p.ldc = l->y_ld;
     p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
@@ -790,6 +798,10 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
     DLRM_REQUIRE(l->d_dz && l->d_w && l->d_dx, "NULL operand");
     DLRM_REQUIRE(l->dz_ld >= l->N && l->w_ld >= l->K && l->dx_ld >= l->K, "leading dimension too small");
+    if (l->N == 1 && gemv_ok(l->d_dx, l->dx_ld, l->d_w, l->K) &&
+        (l->d_relu_mask == nullptr || gemv_ok(l->d_relu_mask, l->relu_mask_ld, l->d_w, l->K)))
+        return gemv_backward_data(l->d_dz, l->dz_ld, l->d_w, l->d_dx, l->dx_ld, l->d_relu_mask, l->relu_mask_ld, (int)l->M,
+                                  l->K, as_stream(stream));
     GemmParams p{};
     p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_dx; p.ldc = l->dx_ld;
     p.M = (int)l->M; p.N = l->K; p.K = l->N;  // C = dx [M,K], reduction over N
@@ -823,6 +835,25 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
     const int tiles = (int)(ceil_div(l->N, BM) * ceil_div(l->K, BN));
     const int splits = choose_splits((int)l->M, tiles);
     float *slabs = static_cast<float *>(d_workspace);
+    const bool few_inputs = skinny_k_forward_ok(l->N, l->K);
+    if (few_inputs || (l->N == 1 && gemv_backward_weight_ok(l->d_x, l->x_ld, l->K))) {
+        // partial sums over row ranges, then the same fixed-order reduction as the split-batch product
+        float *dbp = l->d_db ? slabs + (size_t)splits * l->N * l->K : nullptr;
+        int chunks = 0;
+        const int rc = few_inputs ? skinny_k_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->N,
+                                                             l->K, splits, &chunks, s)
+                                  : gemv_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->K, splits,
+                                                         &chunks, s);
+        if (rc) return rc;
+        const int64_t n = (int64_t)l->N * l->K;
+        const unsigned blocks = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, chunks, n, l->N, l->K, l->d_dw, l->dw_ld);
+        if (l->d_db)
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 64)), dim3(256), 0, s, dbp, chunks,
+                               (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
+        DLRM_LAUNCH_CHECK();
+        return DLRM_OK;
+    }
     GemmParams p{};
     p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_x; p.ldb = l->x_ld;
     p.M = l->N; p.N = l->K; p.K = (int)l->M;  // C = dW [N,K], reduction over the batch

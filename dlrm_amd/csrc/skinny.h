@@ -1,0 +1,32 @@
+// Layers that are no matrix product: a 13-wide input (Criteo's dense features) or a single output (the
+// click logit).  They are bound by reading or writing their one large operand; the MFMA tile kernels
+// spend a whole 128 x 128 x 32 step on them.
+#pragma once
+#include "common.h"
+
+namespace dlrm {
+
+constexpr int kSkinnyK = 16;   // widest reduction the column-per-thread kernels take
+
+// y = act(x W^T + b) with K <= kSkinnyK
+bool skinny_k_forward_ok(int N, int K);
+int skinny_k_forward(const float *x, int64_t x_ld, const float *w, int64_t w_ld, const float *bias, float *y, int64_t y_ld,
+                     int M, int N, int K, int relu, hipStream_t s);
+// partial sums of dW = dz^T x and db = column sums of dz over `chunks` row ranges (chunks <= max_chunks):
+// slabs [chunks][N][K], db_slabs [chunks][N] (or NULL).  The caller adds the chunks up.
+int skinny_k_backward_weight(const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, float *slabs, float *db_slabs,
+                             int M, int N, int K, int max_chunks, int *chunks, hipStream_t s);
+
+// N == 1: y[m] = act(x[m,:] . w + b)
+bool gemv_ok(const void *x, int64_t x_ld, const void *w, int K);
+int gemv_forward(const float *x, int64_t x_ld, const float *w, const float *bias, float *y, int64_t y_ld, int M, int K, int relu,
+                 hipStream_t s);
+// dx[m,k] = dz[m] w[k], zero where mask[m,k] <= 0
+int gemv_backward_data(const float *dz, int64_t dz_ld, const float *w, float *dx, int64_t dx_ld, const float *mask,
+                       int64_t mask_ld, int M, int K, hipStream_t s);
+// partial sums of dw[k] = sum_m dz[m] x[m,k] and db = sum_m dz[m]: slabs [chunks][K], db_slabs [chunks]
+bool gemv_backward_weight_ok(const void *x, int64_t x_ld, int K);
+int gemv_backward_weight(const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, float *slabs, float *db_slabs, int M,
+                         int K, int max_chunks, int *chunks, hipStream_t s);
+
+}  // namespace dlrm

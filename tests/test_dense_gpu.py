@@ -34,6 +34,11 @@ SHAPES = [
     (2048, 256, 512),
     (130, 130, 130),    # nothing a multiple of the tile
     (1, 7, 5),
+    (9000, 512, 13),    # layers that are no matrix product: a few input columns ...
+    (333, 64, 16),
+    (9000, 1, 256),     # ... or a single output column (several workgroups' partial sums in the weight gradient)
+    (70, 1, 1024),
+    (45, 1, 12),
 ]
 
 
