@@ -21,7 +21,7 @@ class DlrmError(RuntimeError):
     pass
 
 
-ABI_VERSION = 1005   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
+ABI_VERSION = 1006   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
 
 
 class EmbBagDesc(C.Structure):

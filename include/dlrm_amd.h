@@ -51,7 +51,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1005
+#define DLRM_ABI_VERSION 1006
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -519,6 +519,33 @@ int dlrm_vcache_export_table(dlrm_vcache *c, int32_t table, int32_t *h_row_slot,
  * (epoch << 32) | position of the first request: smaller = older), hit count.  Synchronises. */
 int dlrm_vcache_export_slots(dlrm_vcache *c, int32_t *h_slot_row, uint64_t *h_slot_key, int32_t *h_slot_count,
                              dlrm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Collectives of the sharded step (RCCL over xGMI), for hosts without a Python runtime.  No counterpart in the
+ * reference, which runs on one host; the placement follows its striping of tables over parallel units
+ * (include/data2.h:150, src/emb_cache2.cpp:701-709): whole tables per rank -> all-to-all of the pooled vectors
+ * [B_local, tables of the sender, dim] and of their gradients; row ranges per rank
+ * (dlrm_embbag.d_shard_row_begin) -> reduce-scatter of partial sums, all-gather of gradients; dense
+ * gradients -> all-reduce.  One communicator per process, created with the HIP device current that its
+ * calls will use; calls are enqueued on the given stream; every rank makes the same calls in the same order.
+ * ------------------------------------------------------------------------ */
+typedef struct dlrm_comm dlrm_comm;
+#define DLRM_COMM_ID_BYTES 128
+/* Rank 0 draws an id and hands it to the other ranks by any means (file, environment, socket). */
+int dlrm_comm_unique_id(uint8_t *id /* [DLRM_COMM_ID_BYTES] */);
+int dlrm_comm_init(const uint8_t *id, int32_t rank, int32_t world, dlrm_comm **out);
+int dlrm_comm_destroy(dlrm_comm *c);
+/* d_buf[i] = sum over ranks, in place (the flat MLP gradient buffer). */
+int dlrm_comm_all_reduce_sum(dlrm_comm *c, float *d_buf, int64_t n, dlrm_stream_t stream);
+/* Floats for peer p are h_send_counts[p] consecutive elements of d_send (peers in rank order); what peer p
+ * sends arrives as h_recv_counts[p] consecutive elements of d_recv. */
+int dlrm_comm_all_to_all(dlrm_comm *c, const float *d_send, const int64_t *h_send_counts, float *d_recv,
+                         const int64_t *h_recv_counts, dlrm_stream_t stream);
+/* d_recv[i] = sum over ranks of their d_send[rank * recv_count + i]. */
+int dlrm_comm_reduce_scatter_sum(dlrm_comm *c, const float *d_send, float *d_recv, int64_t recv_count,
+                                 dlrm_stream_t stream);
+/* d_recv[p * send_count + i] = rank p's d_send[i]. */
+int dlrm_comm_all_gather(dlrm_comm *c, const float *d_send, float *d_recv, int64_t send_count, dlrm_stream_t stream);
 
 #ifdef __cplusplus
 }
