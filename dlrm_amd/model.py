@@ -595,10 +595,10 @@ class DLRM:
             self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
                                                  self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
         items.append(("ops", "main", bottom_backward))
-        items.append(("wait", "main", "emb"))     # rows are updated before anyone reuses dfeat
         if self.world > 1:
-            import torch.distributed as dist
+            # every dense gradient is complete: the all-reduce runs beside the sparse row update of the other stream
             items.append(("host", "main", lambda: self._all_reduce(self.grads)))
+        items.append(("wait", "main", "emb"))     # rows are updated before anyone reuses dfeat
         items.append(("ops", "main", lambda: ops.sgd_step_(self.params, self.grads, cfg.lr)))
         return items
 
