@@ -23,6 +23,7 @@ def tables():
     """All 26 tables of the MLPerf shape, uniform [0,1), in one 96 GB allocation."""
     from dlrm_amd import ops
     from dlrm_amd.model import MLPERF_TABLE_ROWS
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     total = sum(MLPERF_TABLE_ROWS)
     if free < total * D * 4 + (24 << 30):
@@ -129,6 +130,7 @@ def test_train_step_is_reproducible_at_full_size():
     from dlrm_amd.data import synthetic_batch
     from dlrm_amd.model import DLRM, DLRMConfig
     cfg = DLRMConfig.mlperf(lr=1e-4)       # small steps: the repeated batch must fit better every time
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < sum(cfg.table_rows) * cfg.dim * 4 + (24 << 30):
         pytest.skip("needs the 96 GB of tables plus work buffers in HBM")
