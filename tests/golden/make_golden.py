@@ -92,8 +92,8 @@ def loss_case(rng, n):
 
 
 def as_shipped_step(rng):
-    """One batch of the reference loop exactly as it executes (SURVEY quirks
-    Q1-Q7, Q10): per table a mini-table of the batch's SORTED ids, mean pooling
+    """One batch of the reference loop exactly as it executes
+    (src/dlrmtest.cpp:53-107, :170-206, :499-535): per table a mini-table of the batch's SORTED ids, mean pooling
     over consecutive groups of L sorted ids, concat with the bottom MLP output,
     ReLU on every layer, MSE; SGD(lr 0.01) updates the mini-table of table 0
     only; rows are written back in sorted order (last duplicate wins)."""
