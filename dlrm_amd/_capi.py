@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdlrm_amd.so")
+LIB_PATH = os.environ.get("DLRM_AMD_LIB") or os.path.join(_HERE, "lib", "libdlrm_amd.so")   # (override: A/B builds)
 
 OK = 0
 F32, BF16 = 0, 1
