@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="embedding side on the caller's stream")
     ap.add_argument("--overlap", action="store_true", help="embedding side on its own stream (default for N>1)")
     ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")
+    ap.add_argument("--wgrad-stream", default="auto", choices=["auto", "on", "off"],
+                    help="MLP weight gradients on their own stream beside the data gradients (auto: local batch <= 32768)")
     ap.add_argument("--progress", action="store_true", help="synchronise and print a line to stderr after every step")
     ap.add_argument("--watchdog", type=int, default=0,
                     help="seconds after which a run that has not finished dumps every thread's stack and exits")
@@ -219,7 +221,8 @@ def main():
                  cache_fraction=args.cache_fraction if cached else None,
                  cache_rows_per_page=args.cache_rows_per_page, replay=not args.eager, cache_policy=args.cache_policy,
                  cache_log_pages=((args.steps + args.warmup + 2) * Bg * cfg.lookups) // 8 + 64,
-                 overlap=False if args.no_overlap else (True if args.overlap else None), presort=False if args.no_presort else None)
+                 overlap=False if args.no_overlap else (True if args.overlap else None), presort=False if args.no_presort else None,
+                 wgrad_stream={"auto": None, "on": True, "off": False}[args.wgrad_stream])
     local_rows = [cfg.table_rows[t] for t in model.local_table_ids]   # ids are global: full table sizes
 
     # a few different batches, resident in HBM, cycled

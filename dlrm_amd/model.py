@@ -176,7 +176,7 @@ class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
                  seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
                  cache_rows_per_page=1, replay=False, presort=None, cache_policy="lru",
-                 cache_log_pages=4096):
+                 cache_log_pages=4096, wgrad_stream=None):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
@@ -186,6 +186,10 @@ class DLRM:
         its ids up (misses are filled over the host link), pools and updates rows inside the cache's
         slot pool and reclaims down to the capacity.  `train_step(..., next_indices=...)` looks the next
         batch up on a second stream while this one computes.
+        wgrad_stream: run the weight gradients of the MLPs on their own stream beside the chain of data
+        gradients (both only need a layer's dz).  Default: when the local batch is small (<= 16384 samples):
+        then most layers have fewer tiles than the chip has compute units and the two kernels fill it together;
+        at the full MLPerf batch every kernel fills the chip alone.
         cache_policy: "lru" (pages or rows, least recently used: `class cache`) or "vec" (the reference's
         `class cache2`, dlrm_amd.vcache.VectorCache: rows cached one by one, every table lists up to
         cache_fraction x (rows of the largest table) rows oldest request first, evicted rows are repacked
@@ -327,6 +331,9 @@ class DLRM:
         if overlap is None:
             overlap = world > 1
         self.side = torch.cuda.Stream(device=dev) if (overlap and self.dev.type == "cuda") else None
+        if wgrad_stream is None:
+            wgrad_stream = batch <= 32768
+        self.wgrad = torch.cuda.Stream(device=dev) if (wgrad_stream and self.dev.type == "cuda") else None
 
         # ---- exchange buffers (sharded only)
         if world > 1:
@@ -560,41 +567,66 @@ class DLRM:
         items.append(("ops", "main", top))
         return items
 
+    def _mlp_backward_items(self, stack, x_in, acts, dz_last, dz_bufs, dx_first=None):
+        """MLPStack.backward as schedule items.  With a weight-gradient stream every layer's dW / db kernels go
+        there (they wait for the layer's dz) while the data gradients continue on the caller's stream."""
+        if self.wgrad is None:
+            def whole():
+                self.ws_dense = stack.backward(x_in, acts, dz_last, dz_bufs, self.ws_dense, dx_first=dx_first)
+            return [("ops", "main", whole)]
+        items = []
+        for i in reversed(range(stack.n_layers)):
+            dz = dz_last if i == stack.n_layers - 1 else dz_bufs[i]
+            x = x_in if i == 0 else acts[i - 1]
+
+            def wgrad(dz=dz, x=x, i=i):
+                _, _, self.ws_dense = ops.linear_backward_weight(dz, x, dw=stack.dW[i], db=stack.db[i],
+                                                                 workspace=self.ws_dense)
+            items.append(("wait", "wgrad", "main"))          # dz of this layer is complete
+            items.append(("ops", "wgrad", wgrad))
+            if i > 0:
+                items.append(("ops", "main", lambda dz=dz, i=i: ops.linear_backward_data(
+                    dz, stack.W[i], relu_mask=acts[i - 1], out=dz_bufs[i - 1])))
+            elif dx_first is not None:
+                items.append(("ops", "main", lambda dz=dz: ops.linear_backward_data(dz, stack.W[0], out=dx_first)))
+        return items
+
     def _train_items(self, indices, offsets):
         """One iteration of the reference's loop body (src/dlrmtest.cpp:505-535)."""
         cfg = self.cfg
         items = self._forward_items(indices, offsets, train=True)
 
-        def loss_and_top_backward():
+        def loss_fn():
             if cfg.loss == "bce":
                 ops.loss_bce_logits(self.pred.view(-1), self.labels, loss=self.loss, dlogit=self.dpred.view(-1),
                                     mean_over=self.Bg)
             else:
                 ops.loss_mse(self.pred.view(-1), self.labels, relu_mask_pred=cfg.final_relu, loss=self.loss,
                              dpred=self.dpred.view(-1), mean_over=self.Bg)
-            if cfg.interaction == "dot":
-                self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
-                                                  self.ws_dense, dx_first=self.dinter[:, :cfg.top_in])
-                ops.interact_dot_backward(self.feat.view(self.B, cfg.num_features, cfg.dim),
-                                          self.dinter[:, :cfg.top_in], relu_mask_feature0=True,
-                                          out=self.dfeat.view(self.B, cfg.num_features, cfg.dim))
-            else:
-                self.ws_dense = self.top.backward(self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
-                                                  self.ws_dense, dx_first=None)
+        items.append(("ops", "main", loss_fn))
+        if cfg.interaction == "dot":
+            items += self._mlp_backward_items(self.top, self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz,
+                                              dx_first=self.dinter[:, :cfg.top_in])
+            items.append(("ops", "main", lambda: ops.interact_dot_backward(
+                self.feat.view(self.B, cfg.num_features, cfg.dim), self.dinter[:, :cfg.top_in], relu_mask_feature0=True,
+                out=self.dfeat.view(self.B, cfg.num_features, cfg.dim))))
+        else:
+            items += self._mlp_backward_items(self.top, self.inter[:, :cfg.top_in], self.top_acts, self.dpred, self.top_dz)
+
+            def concat_backward():
                 nb = cfg.bottom[-1]
                 dz0 = self.top_dz[0] if self.top.n_layers > 1 else self.dpred
                 # bottom part of the concatenation is a ReLU output, the pooled part is not
                 ops.linear_backward_data(dz0, self.top.W[0][:, :nb], relu_mask=self.feat[:, :nb], out=self.dfeat[:, :nb])
                 ops.linear_backward_data(dz0, self.top.W[0][:, nb:], out=self.dfeat[:, nb:cfg.top_in])
-        items.append(("ops", "main", loss_and_top_backward))
+            items.append(("ops", "main", concat_backward))
         # sparse rows (exchange + fused update) beside the bottom MLP's backward
         items.append(("wait", "emb", "main"))     # dfeat is complete
         items += self._emb_backward_items(indices, offsets)
 
-        def bottom_backward():
-            self.ws_dense = self.bottom.backward(self.x_dense[:, :cfg.dense_in], self.bot_acts,
-                                                 self.dfeat[:, :cfg.bottom[-1]], self.bot_dz, self.ws_dense)
-        items.append(("ops", "main", bottom_backward))
+        items += self._mlp_backward_items(self.bottom, self.x_dense[:, :cfg.dense_in], self.bot_acts,
+                                          self.dfeat[:, :cfg.bottom[-1]], self.bot_dz)
+        items.append(("wait", "main", "wgrad"))   # every dense gradient is there
         if self.world > 1:
             # every dense gradient is complete: the all-reduce runs beside the sparse row update of the other stream
             items.append(("host", "main", lambda: self._all_reduce(self.grads)))
@@ -605,7 +637,8 @@ class DLRM:
     def _streams(self):
         main = torch.cuda.current_stream() if self.dev.type == "cuda" else None
         return {"main": main, "emb": self.side if self.side is not None else main,
-                "prep": self.prep if self.prep is not None else main}
+                "prep": self.prep if self.prep is not None else main,
+                "wgrad": self.wgrad if self.wgrad is not None else main}
 
     def _run_items(self, items, plan=None):
         """Executes a schedule.  Without a plan the "ops" items launch their operators now; with one,
