@@ -54,7 +54,8 @@ class KernelTimer:
             e0.record()
             r = orig(*a, **kw)
             e1.record()
-            timer.records.append((name, e0, e1, work_fn(*a, **kw), kind))
+            key, work, knd = classify(name, a, kw, work_fn(*a, **kw), kind)
+            timer.records.append((key, e0, e1, work, knd))
             return r
 
         setattr(ops, name, wrapped)
@@ -67,6 +68,25 @@ class KernelTimer:
             d["work"] += work
             d["launches"] += 1
         return out
+
+
+def classify(name, a, kw, work, kind):
+    """Layers that are no matrix product (13 input columns, one output column) run in the one-pass kernels of
+    skinny.hip: they are listed on their own, priced by the bytes of their large operands."""
+    if name == "linear_forward":
+        M, (N, K) = a[0].shape[0], a[1].shape
+        if (K <= 16 and N >= 64) or N == 1:
+            return name + "_skinny", 4.0 * M * (N + K), "hbm"
+    elif name == "linear_backward_data":
+        M, (N, K) = a[0].shape[0], a[1].shape
+        if N == 1:
+            masked = len(a) > 2 and a[2] is not None or kw.get("relu_mask") is not None
+            return name + "_skinny", 4.0 * M * (N + K * (2 if masked else 1)), "hbm"
+    elif name == "linear_backward_weight":
+        M, N, K = a[0].shape[0], a[0].shape[1], a[1].shape[1]
+        if (K <= 16 and N >= 64) or N == 1:
+            return name + "_skinny", 4.0 * M * (N + K), "hbm"
+    return name, work, kind
 
 
 def install_timers(ops, model_ref):
@@ -130,6 +150,9 @@ KERNEL_OF = {
     "embbag_backward_prepare": "expand_pairs + rocprim radix sort (ids only; overlapped with the forward pass)",
     "interact_dot_forward": "interact_dot_fwd_kernel",
     "interact_dot_backward": "interact_dot_bwd_kernel",
+    "linear_forward_skinny": "skinny_k_fwd_kernel / gemv_fwd_kernel (13 input columns; one output column)",
+    "linear_backward_data_skinny": "gemv_bwd_data_kernel (one output column)",
+    "linear_backward_weight_skinny": "skinny_k_bwd_weight_kernel / gemv_bwd_weight_kernel + reduce_slabs",
 }
 
 
@@ -308,9 +331,10 @@ def main():
             # half (the sort, beside the forward pass on its own stream) is listed on its own: sort
             # scratch traffic is overhead, not algorithmic work
             key = "embbag_backward_update" if name == "embbag_backward_apply" else name
+            key, work, kind = classify(key, a, kw, fn(*a, **kw), kind)
             d = summ.setdefault(key, {"ms": 0.0, "work": 0.0, "launches": 0, "kind": kind})
             d["ms"] += ms[i]
-            d["work"] += fn(*a, **kw) * runs[i]
+            d["work"] += work * runs[i]
             d["launches"] += runs[i]
     kernels = []
     for name, d in summ.items():

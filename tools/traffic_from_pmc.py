@@ -23,6 +23,11 @@ RULES = [
     ("gemm_bf16x3_kernel<false, false>", "linear_backward_weight", True),
     ("gemm_f32_kernel<false, false>", "linear_backward_weight", True),
     ("reduce_slabs_kernel", "linear_backward_weight", False),
+    ("skinny_k_fwd_kernel", "linear_forward_skinny", True),
+    ("gemv_fwd_kernel", "linear_forward_skinny", True),
+    ("gemv_bwd_data_kernel", "linear_backward_data_skinny", True),
+    ("skinny_k_bwd_weight_kernel", "linear_backward_weight_skinny", True),
+    ("gemv_bwd_weight_kernel", "linear_backward_weight_skinny", True),
     ("embbag_fwd", "embbag_forward", True),
     ("expand_pairs_kernel", "embbag_backward_prepare", True),    # ids only: pairs + sort, beside the forward pass
     ("rocprim", "embbag_backward_prepare", False),
