@@ -82,3 +82,33 @@ def test_loss_decreases_on_fixed_batch():
     di, do = torch.from_numpy(idx).cuda(), torch.from_numpy(off).cuda()
     losses = [m.train_step(di, do).item() for _ in range(30)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("name", ["mlperf_like", "kaggle_like", "rmc1_like"])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_inference_matches_oracle_and_changes_nothing(oracle, name, overlap):
+    """DLRM.forward (Net2::forward around emb::forward, src/dlrmtest.cpp:254-272): the predictions of the
+    oracle's forward pass, and no table row or parameter moves."""
+    import copy
+    from dlrm_amd.model import DLRM
+    cfg = small_cfgs()[name]
+    B = 53
+    m = DLRM(cfg, B, seed=9, overlap=overlap)
+    if name == "rmc1_like":
+        for b in m.bottom.b + m.top.b:
+            b.abs_()
+    tables, Ws, bs = get_state(m)
+    rng = np.random.default_rng(23)
+    for _ in range(2):
+        dense, idx, off, labels = make_batch(rng, cfg, B, True)
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        pred = m.forward(torch.from_numpy(idx).cuda(), torch.from_numpy(off).cuda())
+        torch.cuda.synchronize()
+        assert int(m.err_flag.item()) == 0
+        # the oracle's step on copies: its predictions are those of the forward pass before any update
+        _, pred_ref = oracle_train_step(oracle, cfg, copy.deepcopy(tables), copy.deepcopy(Ws), copy.deepcopy(bs), dense, idx,
+                                        off, labels, len(cfg.bottom), cfg.lr)
+        assert rel_err(pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        got_t, got_W, got_b = get_state(m)
+        for a, r in zip(got_t + got_W + got_b, tables + Ws + bs):
+            assert np.array_equal(a, r)
