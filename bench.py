@@ -389,6 +389,29 @@ def main():
                       "table_GB": sum(cfg.table_rows[t] for t in model.local_table_ids) * cfg.dim * 4 / 1e9,
                       "error_flags": int(st.error_flags)}
 
+    # forward only (inference), same batches, after the timed training steps
+    infer = None
+    if not cached:
+        n_inf = max(min(args.steps, 10), 1)
+        for i in range(2):
+            model.forward(batches[i % n_batches][1], batches[i % n_batches][2])
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_inf):
+            dense, idx, off, labels, _ = batches[i % n_batches]
+            model.load_batch(dense, labels)
+            model.forward(idx, off)
+        torch.cuda.synchronize()
+        barrier()
+        dt_inf = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt_inf = float(tt.item())
+        infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
+                 "launch": "eager (one Python call per operator)"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_cpu_baseline
@@ -413,6 +436,7 @@ def main():
                                                         "table-wise + %d row-wise tables" % model.Trw, world))},
             "loss": float(loss.item()),
             "cache": cache_info,
+            "inference": infer,
             "roofline": roofline,
             "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,
             "kernels": kernels,
