@@ -396,21 +396,56 @@ __global__ void plan_reclaim_kernel(Geom g, Dev d) {
     d.scalars[S_N_CAND] = 0;
 }
 
-// every listed slot with a key that sorts by (table, oldest first)
+// every listed slot with a key that sorts by (table, oldest first).  A workgroup takes kCollectPer slots per
+// trip and reserves room for its listed ones with ONE atomic (the order of the candidates does not matter, they
+// are sorted next): a counter that every wave bumps would serialise a scan of tens of millions of slots.
+constexpr int kCollectPer = 16;   // slots per thread and trip
+
 __global__ __launch_bounds__(kThreads) void collect_kernel(Geom g, Dev d) {
+    __shared__ int wave_tot[kThreads / 64];
+    __shared__ long long blk_base;
     const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
-    for (int64_t base = (int64_t)blockIdx.x * kThreads; base < d.S; base += (int64_t)gridDim.x * kThreads) {
-        const int64_t s = base + threadIdx.x;
-        const uint64_t key = s < d.S ? d.slot_key[s] : 0;
-        const bool take = key != 0;
-        const int64_t pos = wave_append(&d.scalars[S_N_CAND], take);
-        if (take) {
-            const int t = table_of(g.row_base, g.T, d.slot_row[s]);
-            const uint32_t age = now - (uint32_t)(key >> 32);
-            const uint64_t inv = kAgeMax - (age < kAgeMax ? age : kAgeMax);
-            d.cand_key[pos] = ((uint64_t)t << 58) | (inv << 32) | (key & 0xffffffffull);
-            d.cand_val[pos] = (int32_t)s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per_trip = (int64_t)kThreads * kCollectPer;
+    for (int64_t base = (int64_t)blockIdx.x * per_trip; base < d.S; base += (int64_t)gridDim.x * per_trip) {
+        uint64_t key[kCollectPer];
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < kCollectPer; u++) {
+            const int64_t s = base + threadIdx.x + (int64_t)u * kThreads;
+            key[u] = s < d.S ? d.slot_key[s] : 0;
+            mine += key[u] != 0;
         }
+        // exclusive prefix of `mine` over the workgroup
+        int incl = mine;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int o = __shfl_up(incl, m, 64);
+            if (lane >= m) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = incl - mine, total = 0;
+        for (int w = 0; w < kThreads / 64; w++) {
+            if (w < wave) before += wave_tot[w];
+            total += wave_tot[w];
+        }
+        if (threadIdx.x == 0)
+            blk_base = total ? (long long)atomicAdd((unsigned long long *)&d.scalars[S_N_CAND], (unsigned long long)total) : 0;
+        __syncthreads();
+        int64_t pos = blk_base + before;
+#pragma unroll
+        for (int u = 0; u < kCollectPer; u++) {
+            if (key[u] == 0) continue;
+            const int64_t s = base + threadIdx.x + (int64_t)u * kThreads;
+            const int t = table_of(g.row_base, g.T, d.slot_row[s]);
+            const uint32_t age = now - (uint32_t)(key[u] >> 32);
+            const uint64_t inv = kAgeMax - (age < kAgeMax ? age : kAgeMax);
+            d.cand_key[pos] = ((uint64_t)t << 58) | (inv << 32) | (key[u] & 0xffffffffull);
+            d.cand_val[pos] = (int32_t)s;
+            pos++;
+        }
+        __syncthreads();   // blk_base and wave_tot are reused by the next trip
     }
 }
 
@@ -821,7 +856,7 @@ extern "C" int dlrm_vcache_reclaim(dlrm_vcache *c, dlrm_stream_t stream) {
     const int64_t n_listed = c->h_scalars[S_N_LISTED], n_evict = c->h_scalars[S_N_EVICT];
     if (n_evict == 0) return DLRM_OK;
     DLRM_REQUIRE(n_listed <= d.S, "internal: %lld listed rows in %lld slots", (long long)n_listed, (long long)d.S);
-    hipLaunchKernelGGL(collect_kernel, dim3(grid_for(d.S)), dim3(kThreads), 0, s, g, d);
+    hipLaunchKernelGGL(collect_kernel, dim3(grid_for(d.S, kThreads * kCollectPer)), dim3(kThreads), 0, s, g, d);
     size_t tmp = 0;
     DLRM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, d.cand_key, d.cand_key_sorted, d.cand_val, d.cand_val_sorted,
                                        (size_t)n_listed, 0u, 64u, s, false));
