@@ -79,6 +79,7 @@ struct Dev {
     int64_t *log_head;     // [T] pages written so far
     int64_t *k_t;          // [T] evictions of the current reclaim
     int64_t *cand_base;    // [T] first position of the table in the sorted candidates
+    int64_t *ev_base;      // [T+1] evictions of the tables before t in the current reclaim
     int64_t *flushes;      // [T] buffers completed by the current reclaim
     int32_t *miss;         // pages to read (global ids)
     uint64_t *cand_key, *cand_key_sorted;
@@ -163,13 +164,40 @@ __device__ inline void copy_row(const Geom &g, char *dst, const char *src, int l
         *reinterpret_cast<uint4 *>(dst + 16 * c) = *reinterpret_cast<const uint4 *>(src + 16 * c);
 }
 
-// A group of kGroup lanes makes row r of table t resident if it is not (unlisted, hit count 0).
-// Returns true for the group that did it.  tail: number of pushes to the free ring before this kernel.
-__device__ inline bool install_row(const Geom &g, const Dev &d, int t, int64_t r, int lig, int64_t tail) {
-    const int64_t gr = g.row_base[t] + r;
+// Ring traffic of a workgroup trip: the lanes that pop (or push) a slot number themselves in LDS, one lane moves
+// the ring's head (or tail) for all of them.  One global atomic per trip instead of one per row: the ring's
+// counters are single addresses that every workgroup of the chip hits.
+struct RingTrip {
+    int *cnt;           // LDS
+    long long *base;    // LDS
+    __device__ void begin() {
+        if (threadIdx.x == 0) *cnt = 0;
+        __syncthreads();
+    }
+    __device__ int take(bool want) { return want ? atomicAdd(cnt, 1) : -1; }
+    __device__ int take_n(int n) { return n ? atomicAdd(cnt, n) : 0; }
+    // after every lane has called take(): first ring position of this trip's slots (all threads must call)
+    __device__ long long reserve(int64_t *counter) {
+        __syncthreads();
+        if (threadIdx.x == 0) *base = *cnt ? (long long)atomicAdd((unsigned long long *)counter, (unsigned long long)*cnt) : 0;
+        __syncthreads();
+        return *base;
+    }
+};
+
+// Every group of kGroup lanes of the workgroup offers one row (t, r) -- or none (valid false) -- that becomes
+// resident if it is not (unlisted, hit count 0).  All threads of the workgroup must call.  Returns true for the
+// groups that installed their row.  tail: number of pushes to the free ring before this kernel.
+__device__ inline bool install_rows(const Geom &g, const Dev &d, RingTrip &ring, bool valid, int t, int64_t r, int lig,
+                                    int64_t tail) {
+    const int64_t gr = valid ? g.row_base[t] + r : 0;
+    ring.begin();
+    const bool want = valid && lig == 0 && d.row_slot[gr] == -1 && atomicCAS(&d.row_slot[gr], -1, -2) == -1;
+    const int my = ring.take(want);
+    const long long first = ring.reserve(&d.scalars[S_HEAD]);
     int32_t s = -1;
-    if (lig == 0 && d.row_slot[gr] == -1 && atomicCAS(&d.row_slot[gr], -1, -2) == -1) {
-        const int64_t idx = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_HEAD], 1ull);
+    if (want) {
+        const int64_t idx = first + my;
         if (idx < tail) {
             s = d.ring[idx % d.S];
         } else {
@@ -248,23 +276,32 @@ __global__ __launch_bounds__(kThreads) void probe_kernel(Geom g, Dev d, IdLayout
 // read(), second half (:865-886): every row a fetched page lists becomes resident
 __global__ __launch_bounds__(kThreads) void fill_kernel(Geom g, Dev d) {
     __shared__ int tally_mem[kMaxTables];
+    __shared__ int ring_cnt;
+    __shared__ long long ring_base;
     BlockTally res{tally_mem};
+    RingTrip ring{&ring_cnt, &ring_base};
     res.clear();
     const int64_t n_miss = d.scalars[S_N_MISS], tail = d.scalars[S_TAIL];
     const int64_t items = n_miss * g.vpo;
     const int lig = threadIdx.x % kGroup;
-    for (int64_t it = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup; it < items;
-         it += (int64_t)gridDim.x * kGroupsPerBlock) {
-        const int64_t q = it / g.vpo;
-        const int j = (int)(it - q * g.vpo);
-        const int64_t gp = d.miss[q];
-        const int t = table_of(g.page_base, g.T, gp);
-        const int64_t lp = gp - g.page_base[t];
-        int64_t r;
-        if (lp < g.n_init[t]) r = lp * g.vpo + j;
-        else r = d.log_rows[((int64_t)t * g.log_cap + (lp - g.n_init[t])) * g.vpo + j];
-        if (r >= g.rows[t]) continue;                       // tail of a table's last initial page
-        if (install_row(g, d, t, r, lig, tail) && lig == 0) res.add(t, 1);
+    const int64_t per_trip = (int64_t)gridDim.x * kGroupsPerBlock;
+    const int64_t trips = (items + per_trip - 1) / per_trip;          // the same for every workgroup
+    for (int64_t trip = 0; trip < trips; trip++) {
+        const int64_t it = trip * per_trip + (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+        bool valid = it < items;
+        int t = 0;
+        int64_t r = 0;
+        if (valid) {
+            const int64_t q = it / g.vpo;
+            const int j = (int)(it - q * g.vpo);
+            const int64_t gp = d.miss[q];
+            t = table_of(g.page_base, g.T, gp);
+            const int64_t lp = gp - g.page_base[t];
+            if (lp < g.n_init[t]) r = lp * g.vpo + j;
+            else r = d.log_rows[((int64_t)t * g.log_cap + (lp - g.n_init[t])) * g.vpo + j];
+            valid = r < g.rows[t];                          // tail of a table's last initial page
+        }
+        if (install_rows(g, d, ring, valid, t, r, lig, tail) && lig == 0) res.add(t, 1);
     }
     res.flush(d.counters, g.T, C_RESIDENT);
 }
@@ -324,19 +361,29 @@ __global__ void finish_lookup_kernel(Dev d) {
 template <typename IDX>
 __global__ __launch_bounds__(kThreads) void restore_kernel(Geom g, Dev d, IdLayout l, const IDX *ids, int64_t n) {
     __shared__ int tally_mem[kMaxTables];
+    __shared__ int ring_cnt;
+    __shared__ long long ring_base;
     BlockTally res{tally_mem};
+    RingTrip ring{&ring_cnt, &ring_base};
     res.clear();
     const int64_t tail = d.scalars[S_TAIL];
     const int lig = threadIdx.x % kGroup;
-    for (int64_t i = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup; i < n;
-         i += (int64_t)gridDim.x * kGroupsPerBlock) {
-        const int t = table_of(l.off, g.T, i);
-        const int64_t id = (int64_t)ids[i];
-        if (id < 0 || id >= g.rows[t]) {
-            if (lig == 0) atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_BAD_ID);
-            continue;
+    const int64_t per_trip = (int64_t)gridDim.x * kGroupsPerBlock;
+    const int64_t trips = (n + per_trip - 1) / per_trip;
+    for (int64_t trip = 0; trip < trips; trip++) {
+        const int64_t i = trip * per_trip + (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+        bool valid = i < n;
+        int t = 0;
+        int64_t id = 0;
+        if (valid) {
+            t = table_of(l.off, g.T, i);
+            id = (int64_t)ids[i];
+            if (id < 0 || id >= g.rows[t]) {
+                if (lig == 0) atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_BAD_ID);
+                valid = false;
+            }
         }
-        if (install_row(g, d, t, id, lig, tail) && lig == 0) res.add(t, 1);
+        if (install_rows(g, d, ring, valid, t, id, lig, tail) && lig == 0) res.add(t, 1);
     }
     res.flush(d.counters, g.T, C_RESIDENT);
 }
@@ -388,9 +435,11 @@ __global__ void plan_reclaim_kernel(Geom g, Dev d) {
         d.k_t[t] = k;
         d.flushes[t] = fl;
         d.cand_base[t] = n_listed;
+        d.ev_base[t] = n_evict;
         n_listed += listed;
         n_evict += k;
     }
+    d.ev_base[g.T] = n_evict;
     d.scalars[S_N_LISTED] = n_listed;
     d.scalars[S_N_EVICT] = n_evict;
     d.scalars[S_N_CAND] = 0;
@@ -473,67 +522,81 @@ __global__ __launch_bounds__(kThreads) void flush_staged_kernel(Geom g, Dev d) {
     }
 }
 
-// Reclaim_vector_page (emb_cache2.cpp:397-633) for every eviction of this reclaim at once: candidate q of the
-// sorted list is eviction number e = q - cand_base[t] of its table (evicted if e < k_t)
-__global__ __launch_bounds__(kThreads) void evict_kernel(Geom g, Dev d, int64_t n_cand) {
+// Reclaim_vector_page (emb_cache2.cpp:397-633) for every eviction of this reclaim at once: eviction j of the call is
+// eviction e = j - ev_base[t] of its table, i.e. candidate cand_base[t] + e of the sorted list
+constexpr int kMaxPush = 1 + (128 + kGroup - 1) / kGroup;   // slots a lane can free in one trip (rows_per_page <= 128)
+
+__global__ __launch_bounds__(kThreads) void evict_kernel(Geom g, Dev d, int64_t n_evict) {
     __shared__ int tally_mem[2][kMaxTables];
+    __shared__ int ring_cnt;
+    __shared__ long long ring_base;
     BlockTally gone{tally_mem[0]}, dropped{tally_mem[1]};
+    RingTrip ring{&ring_cnt, &ring_base};
     gone.clear();
     dropped.clear();
     const int lig = threadIdx.x % kGroup;
-    for (int64_t q = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup; q < n_cand;
-         q += (int64_t)gridDim.x * kGroupsPerBlock) {
-        const int t = (int)(d.cand_key_sorted[q] >> 58);
-        const int64_t e = q - d.cand_base[t];
-        if (e >= d.k_t[t]) continue;
-        const int32_t s = d.cand_val_sorted[q];
-        const int64_t gr = d.slot_row[s], r = gr - g.row_base[t];
-        const int64_t idx = d.pend_n[t] + e;
-        const int64_t grp = idx / g.W;
-        const int w = (int)(idx - grp * g.W);
-        const bool written = grp < d.flushes[t];           // its buffer fills up in this reclaim
-        char *dst;
-        if (written) {
-            const int64_t k = d.log_head[t] + grp * g.ws + w / g.vpo;
-            const int j = w % g.vpo;
-            const int64_t lp = g.n_init[t] + k;
-            dst = g.store[t] + lp * g.page_bytes + (int64_t)j * g.row_bytes;
+    const int64_t per_trip = (int64_t)gridDim.x * kGroupsPerBlock;
+    const int64_t trips = (n_evict + per_trip - 1) / per_trip;       // the same for every workgroup
+    for (int64_t trip = 0; trip < trips; trip++) {
+        const int64_t jev = trip * per_trip + (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+        int32_t freed[kMaxPush];
+        int n_freed = 0;
+        ring.begin();
+        if (jev < n_evict) {
+            const int t = table_of(d.ev_base, g.T, jev);
+            const int64_t e = jev - d.ev_base[t];
+            const int64_t q = d.cand_base[t] + e;
+            const int32_t s = d.cand_val_sorted[q];
+            const int64_t gr = d.slot_row[s], r = gr - g.row_base[t];
+            const int64_t idx = d.pend_n[t] + e;
+            const int64_t grp = idx / g.W;
+            const int w = (int)(idx - grp * g.W);
+            const bool written = grp < d.flushes[t];           // its buffer fills up in this reclaim
+            char *dst;
+            if (written) {
+                const int64_t k = d.log_head[t] + grp * g.ws + w / g.vpo;
+                const int j = w % g.vpo;
+                const int64_t lp = g.n_init[t] + k;
+                dst = g.store[t] + lp * g.page_bytes + (int64_t)j * g.row_bytes;
+                if (lig == 0) {
+                    d.log_rows[((int64_t)t * g.log_cap + k) * g.vpo + j] = (int32_t)r;
+                    d.row_loc[gr] = (int32_t)lp;
+                    d.row_pend[gr] = -1;
+                }
+            } else {
+                dst = d.pend_data + ((int64_t)t * g.W + w) * g.row_bytes;
+                if (lig == 0) {
+                    d.pend_row[(int64_t)t * g.W + w] = (int32_t)r;
+                    d.pend_cnt[(int64_t)t * g.W + w] = d.slot_cnt[s];
+                    d.row_pend[gr] = w;
+                }
+            }
+            copy_row(g, dst, d.data + (int64_t)s * g.row_bytes, lig);
             if (lig == 0) {
-                d.log_rows[((int64_t)t * g.log_cap + k) * g.vpo + j] = (int32_t)r;
-                d.row_loc[gr] = (int32_t)lp;
-                d.row_pend[gr] = -1;
+                // the slot's key stays non-zero until clear_keys_kernel: evictions of neighbouring rows run beside
+                // this one and take a zero key for "unlisted"
+                d.row_slot[gr] = -1;
+                freed[n_freed++] = s;
+                gone.add(t, 1);
             }
-        } else {
-            dst = d.pend_data + ((int64_t)t * g.W + w) * g.row_bytes;
-            if (lig == 0) {
-                d.pend_row[(int64_t)t * g.W + w] = (int32_t)r;
-                d.pend_cnt[(int64_t)t * g.W + w] = d.slot_cnt[s];
-                d.row_pend[gr] = w;
-            }
-        }
-        copy_row(g, dst, d.data + (int64_t)s * g.row_bytes, lig);
-        if (lig == 0) {
-            // the slot's key stays non-zero until clear_keys_kernel: evictions of neighbouring rows run beside
-            // this one and take a zero key for "unlisted"
-            d.row_slot[gr] = -1;
-            const int64_t p = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_TAIL], 1ull);
-            d.ring[p % d.S] = s;
-            gone.add(t, 1);
-        }
-        // unlisted residents of the row's home page are dropped (:492-496); the eviction that fills a buffer
-        // leaves the loop early and only reaches the rows below it (:486-489)
-        const int64_t hp0 = (r / g.vpo) * g.vpo;
-        const bool fills = w == g.W - 1;
-        for (int64_t i = hp0 + lig; i < hp0 + g.vpo && i < g.rows[t]; i += kGroup) {
-            if (i == r || (fills && i > r)) continue;
-            const int64_t gi = g.row_base[t] + i;
-            const int32_t si = d.row_slot[gi];
-            if (si >= 0 && d.slot_key[si] == 0 && atomicCAS(&d.row_slot[gi], si, -1) == si) {
-                const int64_t p = (int64_t)atomicAdd((unsigned long long *)&d.scalars[S_TAIL], 1ull);
-                d.ring[p % d.S] = si;
-                dropped.add(t, 1);
+            // unlisted residents of the row's home page are dropped (:492-496); the eviction that fills a buffer
+            // leaves the loop early and only reaches the rows below it (:486-489)
+            const int64_t hp0 = (r / g.vpo) * g.vpo;
+            const bool fills = w == g.W - 1;
+            for (int64_t i = hp0 + lig; i < hp0 + g.vpo && i < g.rows[t]; i += kGroup) {
+                if (i == r || (fills && i > r)) continue;
+                const int64_t gi = g.row_base[t] + i;
+                const int32_t si = d.row_slot[gi];
+                if (si >= 0 && d.slot_key[si] == 0 && atomicCAS(&d.row_slot[gi], si, -1) == si) {
+                    freed[n_freed++] = si;
+                    dropped.add(t, 1);
+                }
             }
         }
+        // the freed slots of the whole workgroup go back to the ring behind one move of its tail
+        const int my = ring.take_n(n_freed);
+        const long long first = ring.reserve(&d.scalars[S_TAIL]);
+        for (int u = 0; u < n_freed; u++) d.ring[(first + my + u) % d.S] = freed[u];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < g.T; t += kThreads) {
@@ -624,7 +687,7 @@ extern "C" int dlrm_vcache_destroy(dlrm_vcache *c) {
     (void)hipFree(d.slot_key); (void)hipFree(d.slot_cnt); (void)hipFree(d.slot_first); (void)hipFree(d.slot_occ);
     (void)hipFree(d.ring); (void)hipFree(d.scalars); (void)hipFree(d.counters); (void)hipFree(d.page_stamp);
     (void)hipFree(d.log_rows); (void)hipFree(d.pend_row); (void)hipFree(d.pend_cnt); (void)hipFree(d.pend_data);
-    (void)hipFree(d.pend_n); (void)hipFree(d.log_head); (void)hipFree(d.k_t); (void)hipFree(d.cand_base);
+    (void)hipFree(d.pend_n); (void)hipFree(d.log_head); (void)hipFree(d.k_t); (void)hipFree(d.cand_base); (void)hipFree(d.ev_base);
     (void)hipFree(d.flushes); (void)hipFree(d.miss); (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted);
     (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
     if (c->owns_pool) (void)hipFree(d.data);
@@ -638,6 +701,7 @@ extern "C" int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **o
     DLRM_REQUIRE(cfg != nullptr && out != nullptr, "NULL argument");
     DLRM_REQUIRE(cfg->num_tables >= 1 && cfg->num_tables <= kMaxTables, "num_tables must be 1..%d", kMaxTables);
     DLRM_REQUIRE(cfg->dim >= 1 && cfg->rows_per_page >= 1 && cfg->evict_group >= 1, "bad geometry");
+    DLRM_REQUIRE(cfg->rows_per_page <= 128, "rows_per_page %d: at most 128", cfg->rows_per_page);
     DLRM_REQUIRE(cfg->table_rows != nullptr && cfg->h_table_store != nullptr, "table_rows / h_table_store is NULL");
     DLRM_REQUIRE(cfg->num_slots >= 1 && cfg->num_slots < (1ll << 31), "num_slots out of range");
     DLRM_REQUIRE(cfg->log_pages_per_table >= cfg->evict_group, "log_pages_per_table must hold at least one write");
@@ -704,6 +768,7 @@ extern "C" int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **o
     if (!rc) rc = dev_alloc(&d.log_head, T);
     if (!rc) rc = dev_alloc(&d.k_t, T);
     if (!rc) rc = dev_alloc(&d.cand_base, T);
+    if (!rc) rc = dev_alloc(&d.ev_base, T + 1);
     if (!rc) rc = dev_alloc(&d.flushes, T);
     if (!rc) rc = dev_alloc(&d.cand_key, S);
     if (!rc) rc = dev_alloc(&d.cand_key_sorted, S);
@@ -865,7 +930,7 @@ extern "C" int dlrm_vcache_reclaim(dlrm_vcache *c, dlrm_stream_t stream) {
     DLRM_HIP(rocprim::radix_sort_pairs(c->sort_tmp, tmp, d.cand_key, d.cand_key_sorted, d.cand_val, d.cand_val_sorted,
                                        (size_t)n_listed, 0u, 64u, s, false));
     hipLaunchKernelGGL(flush_staged_kernel, dim3(grid_for((int64_t)g.T * g.W, kGroupsPerBlock)), dim3(kThreads), 0, s, g, d);
-    hipLaunchKernelGGL(evict_kernel, dim3(kLinkBlocks), dim3(kThreads), 0, s, g, d, n_listed);
+    hipLaunchKernelGGL(evict_kernel, dim3(kLinkBlocks), dim3(kThreads), 0, s, g, d, n_evict);
     hipLaunchKernelGGL(clear_keys_kernel, dim3(grid_for(n_listed)), dim3(kThreads), 0, s, d, n_listed);
     hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(64), 0, s, g, d);
     DLRM_LAUNCH_CHECK();
