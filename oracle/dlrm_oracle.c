@@ -16,7 +16,9 @@
  *   - the floating point operators restate libtorch CPU operator semantics at
  *     the reference's call sites; the reference has no test or fixture for
  *     them, so they are pinned against fixtures generated in this container
- *     with the same ATen CPU kernels (tests/golden/make_golden.py).
+ *     with the same ATen CPU kernels (tests/golden/make_golden.py); row-wise Adagrad, for which libtorch has
+ *     no operator, against torch.optim.Adagrad on gradients where the two rules coincide
+ *     (tests/test_oracle_golden.py).
  *
  * Every accumulation is done in double and rounded once, so this file is a
  * "closest to exact" comparator for both the HIP path and libtorch.

@@ -83,3 +83,33 @@ def test_reference_loop_as_shipped(oracle):
         assert close(tables[t], c["new_table%d" % t])
     # tables other than 0 are written back unchanged (only table 0 is in the optimizer)
     assert np.array_equal(tables[1], c["table1"])
+
+
+def test_rowwise_adagrad_against_libtorch_adagrad(oracle):
+    """libtorch has no row-wise Adagrad, but where every element of a row's gradient has the same magnitude the
+    row mean of g^2 IS each element's g^2, and the row-wise rule (state += mean g^2; w -= lr g / (sqrt(state) +
+    eps)) must give what torch.optim.Adagrad gives element by element.  Pins the rule's arithmetic (accumulate,
+    then sqrt, eps outside the root) against libtorch's optimizer over three steps."""
+    import torch
+    rng = np.random.default_rng(8)
+    rows, D, B, lr, eps = 50, 16, 20, 0.05, 1e-8
+    w0 = rng.standard_normal((rows, D)).astype(np.float32)
+    w = w0.copy()
+    state = np.zeros(rows, np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = torch.optim.Adagrad([p], lr=lr, eps=eps, initial_accumulator_value=0.0, lr_decay=0.0)
+    for step in range(3):
+        idx = rng.permutation(rows)[:B].astype(np.int64)                  # distinct rows: one bag each
+        off = np.arange(B + 1, dtype=np.int64)
+        mag = rng.uniform(0.1, 2.0, size=(B, 1)).astype(np.float32)
+        g = (mag * rng.choice([-1.0, 1.0], size=(B, D))).astype(np.float32)
+        oracle.embbag_backward_update(w, idx, off, B, g, include_last_offset=True, optimizer=oracle.OPT_ADAGRAD_ROWWISE,
+                                      lr=lr, eps=eps, adagrad_state=state)
+        dense = torch.zeros(rows, D)
+        dense[torch.from_numpy(idx)] = torch.from_numpy(g)
+        # torch's rule touches every element; rows outside the batch have g = 0: state and value unchanged
+        opt.zero_grad()
+        p.grad = dense
+        opt.step()
+        assert np.allclose(w, p.detach().numpy(), rtol=2e-6, atol=1e-7), "step %d" % step
+    assert np.allclose(state, opt.state[p]["sum"].numpy()[:, 0], rtol=1e-6)
