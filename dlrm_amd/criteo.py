@@ -16,18 +16,6 @@ from . import _capi
 from ._capi import check
 
 
-def decode_reference(records, n_dense, n_sparse, table_rows=None):
-    """numpy restatement of the decode (test oracle for the kernel)."""
-    rec = np.asarray(records, dtype=np.int32).reshape(-1, 1 + n_dense + n_sparse)
-    n = rec.shape[0]
-    labels = rec[:, 0].astype(np.float32)
-    dense = np.log1p(np.maximum(rec[:, 1:1 + n_dense], 0).astype(np.float32)).astype(np.float32)
-    ids = rec[:, 1 + n_dense:].astype(np.uint32).astype(np.int64)
-    if table_rows is not None:
-        ids = ids % np.asarray(table_rows, dtype=np.int64)[None, :]
-    return dense, labels, ids.T.reshape(-1).copy(), np.arange(n_sparse * n + 1, dtype=np.int64)
-
-
 class CriteoBinReader:
     def __init__(self, path, batch, table_rows=None, n_dense=13, n_sparse=26, idx_dtype=torch.int32, device="cuda",
                  dense_ld=None):

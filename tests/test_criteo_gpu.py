@@ -9,10 +9,23 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def decode_reference(records, n_dense, n_sparse, table_rows=None):
+    """numpy restatement of dlrm_criteo_decode: label, log(1 + max(x, 0)) dense block, ids as unsigned modulo the
+    table's rows, table-major with one id per bag."""
+    rec = np.asarray(records, dtype=np.int32).reshape(-1, 1 + n_dense + n_sparse)
+    n = rec.shape[0]
+    labels = rec[:, 0].astype(np.float32)
+    dense = np.log1p(np.maximum(rec[:, 1:1 + n_dense], 0).astype(np.float32)).astype(np.float32)
+    ids = rec[:, 1 + n_dense:].astype(np.uint32).astype(np.int64)
+    if table_rows is not None:
+        ids = ids % np.asarray(table_rows, dtype=np.int64)[None, :]
+    return dense, labels, ids.T.reshape(-1).copy(), np.arange(n_sparse * n + 1, dtype=np.int64)
+
+
 @pytest.mark.parametrize("idx_t", [torch.int32, torch.int64])
 @pytest.mark.parametrize("B", [1, 100, 257])
 def test_reader_matches_numpy_decode(tmp_path, idx_t, B):
-    from dlrm_amd.criteo import CriteoBinReader, decode_reference
+    from dlrm_amd.criteo import CriteoBinReader
     rng = np.random.default_rng(B)
     n = 3 * B + B // 2                                 # a tail that is dropped
     rec = np.empty((n, 40), dtype=np.int32)
