@@ -4,15 +4,19 @@
  * One shared library (libdlrm_amd.so) exports everything below.  It replaces,
  * for the data-parallel hot path only, the C++ model interface the reference
  * driver is written against (dlrm_libtorch/src/dlrmtest.cpp with
- * dlrm_libtorch/include/data.h); each entry point cites the reference
- * interface it stands in for.
+ * dlrm_libtorch/include/data.h, and src/dlrmtest2.cpp with include/data2.h for the
+ * second cache policy); each entry point cites the reference interface it stands in for.
+ *
+ * Sections: tables - EmbeddingBag (forward, fused sparse update) - MLP layers - interaction - losses -
+ * recorded step (dlrm_plan) - Criteo record decode - page-LRU cache (dlrm_cache) - vector-granular cache
+ * (dlrm_vcache) - collectives (dlrm_comm).
  *
  * Conventions
  *  - Every function returns DLRM_OK (0) or an error code; the message of the
  *    last error on the calling thread is dlrm_last_error().  Nothing throws.
  *  - Buffers named d_* are device (HBM) pointers owned by the caller; h_* are
  *    host pointers.  The library allocates nothing unless a function says so
- *    (the cache object and the handles are the only owners of device memory).
+ *    (the cache objects and the handles are the only owners of device memory).
  *  - stream is a hipStream_t passed as void*; NULL is the null stream.  All
  *    launches are asynchronous on it; no entry point synchronises unless it
  *    says so.
