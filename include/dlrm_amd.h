@@ -7,9 +7,9 @@
  * dlrm_libtorch/include/data.h, and src/dlrmtest2.cpp with include/data2.h for the
  * second cache policy); each entry point cites the reference interface it stands in for.
  *
- * Sections: tables - EmbeddingBag (forward, fused sparse update) - MLP layers - interaction - losses -
- * recorded step (dlrm_plan) - Criteo record decode - page-LRU cache (dlrm_cache) - vector-granular cache
- * (dlrm_vcache) - collectives (dlrm_comm).
+ * Sections: tables - EmbeddingBag (forward, fused sparse update) - MLP layers - interaction and losses -
+ * page-LRU cache (dlrm_cache: declarations, then its calls further down) - Criteo record decode - recorded
+ * step (dlrm_plan) - vector-granular cache (dlrm_vcache) - collectives (dlrm_comm).
  *
  * Conventions
  *  - Every function returns DLRM_OK (0) or an error code; the message of the
