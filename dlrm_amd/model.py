@@ -176,7 +176,7 @@ class DLRM:
     def __init__(self, cfg: DLRMConfig, batch: int, device="cuda", rank=0, world=1, plan: Optional[ShardingPlan] = None,
                  seed=0, process_group=None, init_tables=True, overlap=None, cache_fraction=None,
                  cache_rows_per_page=1, replay=False, presort=None, cache_policy="lru",
-                 cache_log_pages=4096, wgrad_stream=None):
+                 cache_log_pages=4096, wgrad_stream=None, force_exchange=False):
         """batch: LOCAL batch size (samples whose MLP runs on this rank).
         overlap: run the embedding side (kernels + exchanges) on a second stream beside the bottom
         MLP; default: only when sharded (on one GPU the matrix kernels are power-bound and the
@@ -194,13 +194,17 @@ class DLRM:
         `class cache2`, dlrm_amd.vcache.VectorCache: rows cached one by one, every table lists up to
         cache_fraction x (rows of the largest table) rows oldest request first, evicted rows are repacked
         into new pages of the store; float32 rows, 4096-byte pages; cache_log_pages = pages a table may
-        write over the run)."""
+        write over the run).
+        force_exchange: run the sharded schedule (pack, all-to-all, unpack, reduce-scatter / all-gather of
+        row-wise tables, all-reduce of the dense gradients) even when world == 1, on the process group
+        given: every collective then runs on device buffers in stream order with one rank."""
         _capi.lib()  # fail loudly if the HIP library is missing
         self.cfg, self.B, self.rank, self.world, self.pg = cfg, batch, rank, world, process_group
+        self.sharded = world > 1 or bool(force_exchange)
         self.Bg = batch * world
         self.dev = torch.device(device)
         self.plan = plan or plan_table_wise(cfg.table_rows, world, cfg.dim, 2 if cfg.row_dtype == "bf16" else 4)
-        if world == 1:
+        if not self.sharded:
             # one rank holds everything whole, in the plan's feature order
             self.my_tables, self.rw_tables = list(self.plan.feature_order), []
         else:
@@ -329,14 +333,14 @@ class DLRM:
         # is matrix-pipe bound and the two touch different columns of `feat` / `dfeat`: they can run
         # concurrently, the embedding side on a second HIP stream.
         if overlap is None:
-            overlap = world > 1
+            overlap = self.sharded
         self.side = torch.cuda.Stream(device=dev) if (overlap and self.dev.type == "cuda") else None
         if wgrad_stream is None:
             wgrad_stream = batch <= 32768
         self.wgrad = torch.cuda.Stream(device=dev) if (wgrad_stream and self.dev.type == "cuda") else None
 
         # ---- exchange buffers (sharded only)
-        if world > 1:
+        if self.sharded:
             self.send_splits = [B * self.Tl * D] * world
             self.recv_splits = [B * len(self.plan.tables_of_rank[j]) * D for j in range(world)]
             self.a2a_send = torch.zeros(max(self.Bg * self.Tl * D, 1), **f32)   # [Bg, Tl*D]
@@ -451,7 +455,7 @@ class DLRM:
         the pooled vectors of ALL tables for the local batch."""
         D, B = self.cfg.dim, self.B
         items = []
-        if self.world == 1:
+        if not self.sharded:
             def pool():
                 ops.embbag_forward(out=self.feat[:, self.emb_col0:], out_ld=self.feat.stride(0),
                                    **self._emb_kwargs(indices, offsets))
@@ -497,7 +501,7 @@ class DLRM:
                                                             **self._rw_kwargs(indices, offsets))
         if self.Tl:
             items.append(("ops", "prep", prep_tw))
-        if self.Trw and self.world > 1:
+        if self.Trw and self.sharded:
             items.append(("ops", "prep", prep_rw))
         return items
 
@@ -522,7 +526,7 @@ class DLRM:
                                                                 **kw, **kwargs_fn(indices, offsets))
             return run
         items = [("wait", "emb", "prep")] if self.presort else []
-        if self.world == 1:
+        if not self.sharded:
             return items + [("ops", "emb", update(self._emb_kwargs, self.dfeat[:, self.emb_col0:],
                                                   self.dfeat.stride(0)))]
         import torch.distributed as dist
@@ -627,7 +631,7 @@ class DLRM:
         items += self._mlp_backward_items(self.bottom, self.x_dense[:, :cfg.dense_in], self.bot_acts,
                                           self.dfeat[:, :cfg.bottom[-1]], self.bot_dz)
         items.append(("wait", "main", "wgrad"))   # every dense gradient is there
-        if self.world > 1:
+        if self.sharded:
             # every dense gradient is complete: the all-reduce runs beside the sparse row update of the other stream
             items.append(("host", "main", lambda: self._all_reduce(self.grads)))
         items.append(("wait", "main", "emb"))     # rows are updated before anyone reuses dfeat

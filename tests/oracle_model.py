@@ -4,10 +4,18 @@ import numpy as np
 
 
 def oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, n_bottom, lr, feature_order=None,
-                      mean_over=None, emb_opt_state=None):
+                      mean_over=None, emb_opt_state=None, relu_pattern=None, extras=None):
     """tables: list (global table order) of [rows, D] float32 arrays, updated in place.
     Ws/bs: bottom layers then top layers (float32 arrays, updated in place).
     idx/off: CSR over bags g = t*B + b in GLOBAL table order (include_last_offset).
+    relu_pattern: optional list (bottom layers then top layers) of [B, N_i] arrays whose sign pattern (> 0)
+    replaces the oracle's own activations as the ReLU mask of the backward pass.  A pre-activation within
+    rounding of zero may be positive on one side and zero on the other; at large batch x width a handful of
+    such units exist in every step and each moves a weight gradient by far more than rounding, so a whole-step
+    comparison at 1e-5 is only meaningful at one activation pattern (the forward activations themselves are
+    compared separately).
+    extras: optional dict that receives the oracle's activations ("acts": bottom then top) and the pooled
+    vectors' gradients in global table order ("g_pooled": [B, T, D]).
     Returns (loss, pred)."""
     B = dense.shape[0]
     T, D = len(tables), cfg.dim
@@ -43,9 +51,12 @@ def oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, n_botto
     # top backward
     dy = dpred.reshape(B, 1)
     dWs, dbs = [None] * len(Ws), [None] * len(Ws)
+    pat = (lambda i, own: own) if relu_pattern is None else (lambda i, own: relu_pattern[i])
+    if extras is not None:
+        extras["acts"] = acts[1:] + tacts[1:]
     for i in reversed(range(n_top)):
         relu = cfg.final_relu or i + 1 < n_top
-        dx, dw, db = orc.linear_backward(tacts[i], Ws[n_bottom + i], tacts[i + 1], dy, relu)
+        dx, dw, db = orc.linear_backward(tacts[i], Ws[n_bottom + i], pat(n_bottom + i, tacts[i + 1]), dy, relu)
         dWs[n_bottom + i], dbs[n_bottom + i] = dw, db
         dy = dx
     dinter = dy
@@ -58,6 +69,8 @@ def oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, n_botto
     # pooled grads back to global table order
     g = np.empty((B, T, D), dtype=np.float32)
     g[:, order, :] = dpooled
+    if extras is not None:
+        extras["g_pooled"] = g
     optimizer = orc.OPT_ADAGRAD_ROWWISE if cfg.emb_optimizer == "adagrad" else orc.OPT_SGD
     orc.embbag_backward_update(w_all, idx, off, B, np.ascontiguousarray(g.reshape(B, T * D)), T, tro, pooling, True,
                                optimizer, orc.DUP_ACCUMULATE, lr, cfg.eps, emb_opt_state)
@@ -65,7 +78,7 @@ def oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, n_botto
         tables[t][...] = w_all[tro[t]:tro[t + 1]]
     dy = np.ascontiguousarray(dbot)
     for i in reversed(range(n_bottom)):
-        dx, dw, db = orc.linear_backward(acts[i], Ws[i], acts[i + 1], dy, True, need_dx=i > 0)
+        dx, dw, db = orc.linear_backward(acts[i], Ws[i], pat(i, acts[i + 1]), dy, True, need_dx=i > 0)
         dWs[i], dbs[i] = dw, db
         dy = dx
     for i in range(len(Ws)):

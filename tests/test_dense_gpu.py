@@ -90,6 +90,48 @@ def test_linear_backward(oracle, M, N, K, relu):
     assert rel_err(db.cpu().numpy(), db_ref) <= 1e-5
 
 
+EPS32 = 2.0 ** -24
+
+
+def elementwise_excess(got, ref, scale):
+    """max over elements of (|got - ref| - 1e-5 |ref|) / (2^-24 * scale): how many units of float32 rounding of
+    the element's own absolute sum  scale_ij = sum_k |a_ik b_kj|  the error exceeds 1e-5 relative by."""
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64)) - 1e-5 * np.abs(ref.astype(np.float64))
+    return float(np.max(err / (EPS32 * np.maximum(scale, 1e-300))))
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 367), (2048, 1024, 479), (4096, 1024, 1024), (300, 256, 512),
+                                   (8192, 256, 512)])
+def test_linear_elementwise_error(oracle, M, N, K, gemm_mode):
+    """Every ELEMENT of the three products of a layer, not only the tensor's norm: |got - ref| <= 1e-5 |ref| +
+    8 * 2^-24 * sum_k |a_ik b_kj|.  The second term is the rounding of a float32 accumulation measured against the
+    element's own absolute sum (a cancelled dot product cannot be asked for 1e-5 of its value: float32
+    accumulation itself, on the CPU reference too, is only good to a few 2^-24 of that sum).  Both evaluations
+    (float32 MFMA chain; three-way bfloat16 split, six cross terms) must stay inside it."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dz = rng.standard_normal((M, N)).astype(np.float32)
+    y_ref = oracle.linear_forward(x, w, b, False)
+    dx_ref, dw_ref, db_ref = oracle.linear_backward(x, w, y_ref, dz, False)
+    ax, aw, adz = np.abs(x).astype(np.float64), np.abs(w).astype(np.float64), np.abs(dz).astype(np.float64)
+    d_x, d_w, d_dz = padded(x), padded(w), padded(dz)
+    y = ops.linear_forward(d_x, d_w, torch.from_numpy(b).cuda(), False)
+    dx = ops.linear_backward_data(d_dz, d_w)
+    dw, db, _ = ops.linear_backward_weight(d_dz, d_x)
+    torch.cuda.synchronize()
+    worst = {
+        "y": elementwise_excess(y.cpu().numpy(), y_ref, ax @ aw.T + np.abs(b)[None, :]),
+        "dx": elementwise_excess(dx.cpu().numpy(), dx_ref, adz @ aw),
+        "dw": elementwise_excess(dw.cpu().numpy(), dw_ref, adz.T @ ax),
+        "db": elementwise_excess(db.cpu().numpy(), db_ref, adz.sum(0)),
+    }
+    print("gemm mode %d  M=%d N=%d K=%d  excess in units of 2^-24*abs-sum: %s" % (gemm_mode, M, N, K, worst))
+    assert max(worst.values()) <= 8.0, worst
+
+
 def test_backward_weight_large_batch_split(oracle):
     """batch large enough that the reduction is split over workgroups"""
     from dlrm_amd import ops

@@ -73,12 +73,18 @@ def _cfg(kind):
                       loss="mse", final_relu=True, pooling="mean", lookups=3, lr=0.02)
 
 
-def _worker(rank, world, port, kind, ret, device="cpu", replay=False):
+def _worker(rank, world, port, kind, ret, device="cpu", replay=False, backend="gloo", force_exchange=False):
     """device "cpu": the CPU oracle stands in for dlrm_amd.ops.  device "cuda": the ranks share GPU 0 and run
-    the HIP kernels; gloo moves the buffers through host memory (RCCL refuses two ranks on one device)."""
+    the HIP kernels; gloo moves the buffers through host memory (RCCL refuses two ranks on one device).
+    backend "nccl" (RCCL) with world 1 and force_exchange: the sharded schedule with every collective on
+    device buffers in stream order."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dlrm_amd import ops
         if device == "cpu":
@@ -99,7 +105,10 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False):
         if hybrid:   # the two biggest tables are split by rows, the rest placed whole
             plan = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=60 if kind == "dot" else 40)
             assert len(plan.row_wise) == 2
-        m = DLRM(cfg, Bl, device=device, rank=rank, world=world, seed=4, plan=plan, replay=replay)
+        m = DLRM(cfg, Bl, device=device, rank=rank, world=world, seed=4, plan=plan, replay=replay,
+                 force_exchange=force_exchange)
+        if force_exchange:
+            assert m.sharded and (device == "cpu" or m.side is not None)   # exchanges on the embedding side's own stream
         dev = m.dev
         host = lambda t: t.detach().cpu().numpy()
         loose = 1.0 if device == "cpu" else 10.0      # float32 MFMA products vs the oracle's double accumulation
@@ -127,7 +136,7 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False):
             sl = slice(rank * Bl, (rank + 1) * Bl)
             m.load_batch(torch.from_numpy(dense[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev))
             loss = m.train_step(torch.from_numpy(idx_l).to(dev), torch.from_numpy(off_l).to(dev))
-            tot = loss.detach().cpu().clone()
+            tot = loss.detach().clone() if backend == "nccl" else loss.detach().cpu().clone()
             dist.all_reduce(tot)                               # per-rank shares add up to the global mean
             loss_ref, pred_ref = oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
                                                    cfg.lr, feature_order=m.plan.feature_order)
@@ -152,3 +161,14 @@ def test_sharded_step_equals_single_process(kind):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, kind, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("kind", ["dot-rw", "cat"])
+def test_forced_exchange_with_one_rank(kind):
+    """DLRM(force_exchange=True) on one rank runs the sharded schedule (every pack / exchange / unpack with
+    one peer) and must still equal the single-process step."""
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(1, port, kind, ret, "cpu", False, "gloo", True), nprocs=1, join=True)
+    assert dict(ret) == {0: True}

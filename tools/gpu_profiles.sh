@@ -1,0 +1,57 @@
+#!/bin/bash
+# Collects the rocprofv3 summaries kept under profiles/: kernel traces (per-kernel average duration) and
+# FETCH_SIZE / WRITE_SIZE passes (HBM-side bytes) of the cache sweeps and of bench.py's other configurations.
+# Every profiled program runs under its own time limit; the script stops at the first failure.
+#   tools/gpu_profiles.sh <tag> [cache|kaggle|b8192|bench ...]
+set -e
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+TAG=${1:-r}
+shift || true
+WHAT=${*:-cache kaggle b8192}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+
+trace() {  # name, program args...
+  local name=$1; shift
+  echo "== kernel trace: $name"
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1
+  python3 $ROOT/tools/prof_summary.py "$OUT/$name" "$OUT/$name" && rm -rf "$OUT/$name"
+}
+pmc() {    # name, counter, program args...
+  local name=$1 ctr=$2; shift 2
+  echo "== pmc $ctr: $name"
+  timeout -s KILL 240 rocprofv3 --pmc "$ctr" --output-format csv -d "$OUT/${name}_$ctr" -- "$@" > "$OUT/${name}_$ctr.log" 2>&1
+  python3 $ROOT/tools/prof_summary.py "$OUT/${name}_$ctr" "$OUT/${name}_$ctr" && rm -rf "$OUT/${name}_$ctr"
+}
+
+for w in $WHAT; do
+  case $w in
+    cache)
+      for rpp in 1 8; do
+        A="python3 $ROOT/tools/cache_sweep.py --fracs 0.125 --rpp $rpp --steps 10"
+        trace cache_rpp$rpp $A
+        pmc cache_rpp$rpp FETCH_SIZE $A
+        pmc cache_rpp$rpp WRITE_SIZE $A
+      done
+      A="python3 $ROOT/tools/cache_sweep.py --policy vec --fracs 0.0625 --steps 10"
+      trace cache_vec $A
+      pmc cache_vec FETCH_SIZE $A
+      pmc cache_vec WRITE_SIZE $A
+      ;;
+    kaggle)
+      trace kaggle python3 $ROOT/bench.py --config kaggle --steps 20 --warmup 3 --no-cpu-baseline
+      ;;
+    b8192)
+      trace b8192 python3 $ROOT/bench.py --global-batch 8192 --steps 20 --warmup 3 --no-cpu-baseline
+      ;;
+    bench)
+      trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+      pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+      pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+      ;;
+  esac
+done
+du -sh "$OUT"
+echo done
