@@ -1,8 +1,15 @@
-// float32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in,
-// f32 accumulate, bit-for-bit a k-ordered fmaf chain) with fused epilogues, for
-// the bottom/top MLP: forward (x W^T + b, ReLU), backward-data
-// (dz W, masked by the previous layer's ReLU) and backward-weight (dz^T x,
-// split over the batch dimension).
+// float32 GEMMs of the bottom/top MLP on the gfx950 matrix cores with fused epilogues: forward
+// (x W^T + b, ReLU), backward-data (dz W, masked by the previous layer's ReLU) and backward-weight
+// (dz^T x, split over the batch dimension, partial slabs added in a fixed order).
+//
+// Operands and results are float32 in memory.  Two kernels evaluate the same product; the layer
+// descriptor's gemm_mode picks one:
+//   gemm_bf16x3_kernel (default)  every element is split exactly into three bf16 pieces when its tile goes
+//                                 from registers to LDS; six cross terms on v_mfma_f32_32x32x16_bf16 with
+//                                 float32 accumulation: float32 accuracy at 8/3 of the float32 matrix rate.
+//                                 Described in front of the kernel, further down.
+//   gemm_f32_kernel               v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit for bit a k-ordered
+//                                 fmaf chain.  Described next.
 //
 // One kernel template covers the three products.  C[i][j] = sum_r A(i,r) B(j,r)
 // where each operand is addressed either with the reduction index contiguous
@@ -12,7 +19,7 @@
 //     backward data  : A = dz (RC), B = W (RS)       C = dx [M,K]
 //     backward weight: A = dz (RS), B = x (RS)       C = dW [N,K]   (reduction over M)
 //
-// Tiling: 128x128 output tile per 256-thread workgroup, 32-deep reduction
+// gemm_f32_kernel.  128x128 output tile per 256-thread workgroup, 32-deep reduction
 // steps, 2x2 waves each owning 64x64 (2x2 MFMA tiles of 32x32, 64 accumulator
 // registers).  Global -> registers -> LDS with the next step's loads issued
 // before the current step's MFMAs (double-buffered LDS, one barrier per step).
@@ -719,22 +726,14 @@ __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__
         w[i] -= lr * g[i];
 }
 
-static int g_gemm_mode = -1;   // -1: not chosen yet (environment, else default); 0: f32 MFMA; 1: bf16x3 split
-
-static int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char *e = getenv("DLRM_GEMM_MODE");
-        g_gemm_mode = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_gemm_mode;
-}
-
 template <bool A_RC, bool B_RC>
-static int launch_gemm(GemmParams p, int splits, hipStream_t s) {
+static int launch_gemm(GemmParams p, int splits, int mode, hipStream_t s) {
+    DLRM_REQUIRE(mode == DLRM_GEMM_DEFAULT || mode == DLRM_GEMM_F32_MFMA || mode == DLRM_GEMM_BF16X3,
+                 "gemm_mode must be DLRM_GEMM_DEFAULT, _F32_MFMA or _BF16X3, got %d", mode);
     p.gx = (int)ceil_div(p.N, BN); p.gy = (int)ceil_div(p.M, BM); p.gz = splits;
     const int64_t nwg = (int64_t)p.gx * p.gy * p.gz;
     DLRM_REQUIRE(nwg < (1ll << 31), "GEMM grid too large");
-    if (gemm_mode() == 1)
+    if (mode != DLRM_GEMM_F32_MFMA)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
@@ -761,14 +760,6 @@ static int choose_splits(int M_red, int tiles) {
 
 using namespace dlrm;
 
-extern "C" int dlrm_set_gemm_mode(int32_t mode) {
-    DLRM_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (f32 MFMA) or 1 (bf16x3 split), got %d", mode);
-    g_gemm_mode = mode;
-    return DLRM_OK;
-}
-
-extern "C" int dlrm_get_gemm_mode(void) { return gemm_mode(); }
-
 extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     DLRM_REQUIRE(l != nullptr, "linear descriptor is NULL");
     DLRM_REQUIRE(l->M >= 0 && l->N >= 1 && l->K >= 1, "bad shape M=%lld N=%d K=%d", (long long)l->M, l->N, l->K);
@@ -788,7 +779,7 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->K, BK) * BK;
-    return launch_gemm<true, true>(p, 1, as_stream(stream));
+    return launch_gemm<true, true>(p, 1, l->gemm_mode, as_stream(stream));
 }
 
 extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream) {
@@ -808,7 +799,7 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     p.mask = l->d_relu_mask; p.mask_ld = l->relu_mask_ld;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->N, BK) * BK;
-    return launch_gemm<true, false>(p, 1, as_stream(stream));
+    return launch_gemm<true, false>(p, 1, l->gemm_mode, as_stream(stream));
 }
 
 extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes) {
@@ -863,12 +854,12 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
     if (splits == 1) {
         p.C = l->d_dw; p.ldc = l->dw_ld;
         p.colsum = l->d_db;
-        if (int rc = launch_gemm<false, false>(p, 1, s)) return rc;
+        if (int rc = launch_gemm<false, false>(p, 1, l->gemm_mode, s)) return rc;
     } else {
         p.C = slabs; p.ldc = l->K; p.slab_stride = (int64_t)l->N * l->K;
         p.colsum = l->d_db ? db_partial : nullptr;
         const int real_splits = (int)ceil_div(l->M, p.k_per_split);
-        if (int rc = launch_gemm<false, false>(p, real_splits, s)) return rc;
+        if (int rc = launch_gemm<false, false>(p, real_splits, l->gemm_mode, s)) return rc;
         const int64_t n = (int64_t)l->N * l->K;
         const unsigned blocks = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, real_splits, p.slab_stride,

@@ -4,6 +4,7 @@ torch supplies device memory and the current stream only; every computation
 here is a hand-written HIP kernel inside libdlrm_amd.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,6 +19,7 @@ def _stream():
 # While a StepRecorder is installed (dlrm_amd.plan), the operators below do everything except launch:
 # their C-ABI call is handed to the recorder, which appends it to a dlrm_plan.
 _recorder = None
+_gemm_mode = 0 if os.environ.get("DLRM_GEMM_MODE", "1").strip() == "0" else 1
 
 
 def _emit(name, *args):
@@ -221,6 +223,7 @@ def linear_forward(x, w, bias, relu, out=None):
     d.d_bias = 0 if bias is None else bias.data_ptr()
     d.d_y, d.y_ld = out.data_ptr(), _ld(out)
     d.act = _capi.ACT_RELU if relu else _capi.ACT_NONE
+    d.gemm_mode = _gemm_field()
     _emit("linear_forward", d)
     return out
 
@@ -240,6 +243,7 @@ def linear_backward_data(dz, w, relu_mask=None, out=None):
     d.d_dx, d.dx_ld = out.data_ptr(), _ld(out)
     if relu_mask is not None:
         d.d_relu_mask, d.relu_mask_ld = relu_mask.data_ptr(), _ld(relu_mask)
+    d.gemm_mode = _gemm_field()
     _emit("linear_backward_data", d)
     return out
 
@@ -269,6 +273,7 @@ def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True
     d.d_x, d.x_ld = x.data_ptr(), _ld(x)
     d.d_dw, d.dw_ld = dw.data_ptr(), _ld(dw)
     d.d_db = 0 if db is None else db.data_ptr()
+    d.gemm_mode = _gemm_field()
     _emit("linear_backward_weight", d, _ptr(workspace), C.c_size_t(workspace.numel()))
     return dw, db, workspace
 
@@ -344,10 +349,19 @@ def copy_2d_(dst, src):
 
 
 def set_gemm_mode(mode):
-    """0: float32 MFMA (v_mfma_f32_32x32x2_f32); 1: exact bf16x3 split products on the bf16 MFMA
-    with float32 accumulation (float32 accuracy, 8/3 of the matrix-pipe rate)."""
-    check(_capi.lib().dlrm_set_gemm_mode(int(mode)))
+    """How the linear operators issued from now on evaluate their float32 products (a field of every layer
+    descriptor, so a recorded step keeps the mode it was recorded with): 0 float32 MFMA
+    (v_mfma_f32_32x32x2_f32); 1 exact bf16x3 split products on the bf16 MFMA with float32 accumulation
+    (float32 accuracy, 8/3 of the matrix-pipe rate; the default).  Environment: DLRM_GEMM_MODE=0|1."""
+    global _gemm_mode
+    if int(mode) not in (0, 1):
+        raise ValueError("gemm mode must be 0 (float32 MFMA) or 1 (bf16x3 split)")
+    _gemm_mode = int(mode)
 
 
 def get_gemm_mode():
-    return int(_capi.lib().dlrm_get_gemm_mode())
+    return _gemm_mode
+
+
+def _gemm_field():
+    return _capi.GEMM_F32_MFMA if _gemm_mode == 0 else _capi.GEMM_BF16X3

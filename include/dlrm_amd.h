@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1006
+#define DLRM_ABI_VERSION 1007
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -166,13 +166,26 @@ int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_
 /* ------------------------------------------------------------- dense MLP */
 
 /*
+ * How a layer's float32 products are evaluated on the matrix cores (no counterpart in the reference,
+ * whose GEMMs are libtorch sgemm calls).  Operands and results are float32 in memory either way.
+ *   DLRM_GEMM_BF16X3 (what DLRM_GEMM_DEFAULT selects): every operand element is split exactly into three
+ *      bf16 pieces and the product is formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16
+ *      with float32 accumulation.  Products of pieces are exact in float32 and the dropped terms are below
+ *      2^-26 of a product, so the result has float32 accuracy (element by element within a few 2^-24 of
+ *      sum_k |a_ik b_kj|, like a float32 fma chain) at 8/3 of the float32 matrix-pipe rate.
+ *   DLRM_GEMM_F32_MFMA: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered float32 fma chain.
+ * The mode is a field of the layer descriptor: a recorded step (dlrm_plan) keeps the mode it was recorded
+ * with, and two host threads can use different modes.
+ */
+enum { DLRM_GEMM_DEFAULT = 0, DLRM_GEMM_F32_MFMA = 1, DLRM_GEMM_BF16X3 = 2 };
+
+/*
  * y = act(x W^T + bias): one torch::nn::Linear + torch::relu of Net2::forward
  * (src/dlrmtest.cpp:254-272; layers made by create_fc, :119-140).  W is [N,K]
- * row-major (torch layout).  float32 on the matrix cores
- * (v_mfma_f32_32x32x2_f32), so results are an exact-f32 k-ordered fma chain.
- * Any shape and leading dimension is accepted (K = 13, 479, ...); operands whose
- * rows start on 16-byte boundaries (pointer 16-byte aligned, leading dimension
- * a multiple of 4 floats) are read with 16-byte loads, others with 4-byte loads.
+ * row-major (torch layout).  Any shape and leading dimension is accepted (K = 13, 479, ...);
+ * operands whose rows start on 16-byte boundaries (pointer 16-byte aligned, leading dimension
+ * a multiple of 4 floats) are read with 16-byte loads, others with 4-byte loads.  Layers with at most
+ * 16 inputs or a single output are no matrix product and run in one-pass float32 fma kernels.
  */
 typedef struct dlrm_linear {
     int64_t M;          /* rows of x (batch) */
@@ -185,21 +198,10 @@ typedef struct dlrm_linear {
     float *d_y;         /* [M,N] */
     int64_t y_ld;
     int32_t act;        /* DLRM_ACT_NONE | DLRM_ACT_RELU */
+    int32_t gemm_mode;  /* DLRM_GEMM_* */
 } dlrm_linear;
 
 int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream);
-
-/*
- * How the float32 MLP products are evaluated on the matrix cores (no counterpart in the reference,
- * whose GEMMs are libtorch sgemm calls):
- *   0  v_mfma_f32_32x32x2_f32: float32 operands, an exact k-ordered fma chain
- *   1  (default) every operand element is split exactly into three bf16 pieces and the product is
- *      formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16 with float32
- *      accumulation: float32 accuracy (dropped terms < 2^-26 of a product) at 8/3 of the rate.
- * The process-wide default can also be set with the environment variable DLRM_GEMM_MODE=0|1.
- */
-int dlrm_set_gemm_mode(int32_t mode);
-int dlrm_get_gemm_mode(void);
 
 /*
  * Backward of the same layer; replaces the autograd pass loss.backward()
@@ -231,6 +233,7 @@ typedef struct dlrm_linear_bwd {
     float *d_dw;        /* [N,K]  (backward_weight) */
     int64_t dw_ld;
     float *d_db;        /* [N] or NULL (backward_weight) */
+    int32_t gemm_mode;  /* DLRM_GEMM_* */
 } dlrm_linear_bwd;
 
 int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream);
