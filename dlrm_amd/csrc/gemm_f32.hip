@@ -810,8 +810,8 @@ extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N,
     return DLRM_OK;
 }
 
-extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
-                                           dlrm_stream_t stream) {
+static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
+                                dlrm_stream_t stream) {
     DLRM_REQUIRE(l != nullptr, "linear_bwd descriptor is NULL");
     DLRM_REQUIRE(l->M >= 1 && l->N >= 1 && l->K >= 1, "bad shape");
     DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
@@ -872,6 +872,47 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
         }
     }
     return DLRM_OK;
+}
+
+extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
+                                           dlrm_stream_t stream) {
+    return backward_weight_impl(l, d_workspace, workspace_bytes, stream);
+}
+
+// ---- the same product with the partial-sum slabs in a buffer that is part of the loaded code object ----
+// `scratch` below is the device array; in host code its name is only a handle for hipGetSymbolAddress
+// (every GPU holds its own copy at its own address), so host code uses the looked-up pointer, never the name.
+static __device__ __align__(256) unsigned char scratch[DLRM_STATIC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];   // [device] address of that device's copy of `scratch`, NULL = not asked yet
+
+static int static_scratch(void **out) {
+    int dev = -1;
+    DLRM_HIP(hipGetDevice(&dev));
+    DLRM_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        DLRM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        DLRM_REQUIRE(p != nullptr, "hipGetSymbolAddress returned NULL for the static scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_linear_backward_weight_static(const dlrm_linear_bwd *l, dlrm_stream_t stream) {
+    DLRM_REQUIRE(l != nullptr, "linear_bwd descriptor is NULL");
+    DLRM_REQUIRE(l->M >= 1 && l->N >= 1 && l->K >= 1, "bad shape");
+    size_t need = 0;
+    if (int rc = dlrm_linear_backward_weight_workspace_bytes(l->M, l->N, l->K, &need)) return rc;
+    DLRM_REQUIRE(need <= (size_t)DLRM_STATIC_SCRATCH_BYTES,
+                 "layer M=%lld N=%d K=%d needs %zu bytes of partial sums, the static scratch holds %zu: use "
+                 "dlrm_linear_backward_weight with a workspace", (long long)l->M, l->N, l->K, need,
+                 (size_t)DLRM_STATIC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    if (int rc = static_scratch(&ws)) return rc;
+    return backward_weight_impl(l, ws, (size_t)DLRM_STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int dlrm_sgd_step(float *d_w, const float *d_g, int64_t n, float lr, dlrm_stream_t stream) {

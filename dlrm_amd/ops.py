@@ -278,6 +278,23 @@ def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True
     return dw, db, workspace
 
 
+def linear_backward_weight_static(dz, x, dw, db=None):
+    """linear_backward_weight through the entry point that allocates nothing: partial sums go to the library's
+    static device array (layers beyond its size are refused); outputs must be given."""
+    _require_cuda(dz, x, dw, db)
+    M, N = dz.shape
+    K = x.shape[1]
+    d = _capi.LinearBwdDesc()
+    d.M, d.N, d.K = M, N, K
+    d.d_dz, d.dz_ld = dz.data_ptr(), _ld(dz)
+    d.d_x, d.x_ld = x.data_ptr(), _ld(x)
+    d.d_dw, d.dw_ld = dw.data_ptr(), _ld(dw)
+    d.d_db = 0 if db is None else db.data_ptr()
+    d.gemm_mode = _gemm_field()
+    check(_capi.lib().dlrm_linear_backward_weight_static(C.byref(d), _stream()))
+    return dw, db
+
+
 @_op
 def sgd_step_(w, g, lr):
     _require_cuda(w, g)

@@ -240,6 +240,20 @@ int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream);
 int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes);
 int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
                                 dlrm_stream_t stream);
+/*
+ * dlrm_linear_backward_weight for callers that cannot allocate device memory (code under HIP graph capture,
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same
+ * results bit for bit; the partial sums of the split reduction go to a DLRM_STATIC_SCRATCH_BYTES array that is
+ * part of the library's device code (every GPU the library runs on holds one until the process ends) instead of
+ * a caller workspace.  The call allocates and frees nothing; its first call on a device looks the array's
+ * address up (hipGetSymbolAddress), so make one call before starting a capture.  A layer whose
+ * dlrm_linear_backward_weight_workspace_bytes() exceeds the array is refused with DLRM_ERR_INVALID (every
+ * layer of the Criteo-Kaggle and MLPerf models fits, at any batch).  All calls on one GPU share the array:
+ * calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not.
+ * Nothing in the array has to be zero between calls: every partial sum that is read was written by the same call.
+ */
+#define DLRM_STATIC_SCRATCH_BYTES (40u << 20)
+int dlrm_linear_backward_weight_static(const dlrm_linear_bwd *l, dlrm_stream_t stream);
 
 /*
  * w -= lr * g on a dense tensor.  Replaces torch::optim::SGD::step
