@@ -147,9 +147,11 @@ public:
         check(dlrm_cache_reclaim(h_, nullptr), "dlrm_cache_reclaim");
         refresh();
     }
-    // cache::Reclaim_vector_page (include/data.h:267) evicts from ONE table; the library only
-    // offers the reference driver's policy loop, which is the only caller the reference has.
-    void Reclaim_vector_page(int) { throw std::runtime_error("use reclaim_emb_cache(cache&)"); }
+    // cache::Reclaim_vector_page (include/data.h:267): the ws_opt least recently used pages of ONE table leave
+    void Reclaim_vector_page(int table_ID) {
+        check(dlrm_cache_reclaim_table(h_, table_ID, nullptr), "dlrm_cache_reclaim_table");
+        refresh();
+    }
 
     int get_pu() const { return 8; }   // geo->l.npugrp of the reference's device (CSV labels only)
     void read_page(int i) { reset_one(i, true); }     // include/data.h:274-279
@@ -161,7 +163,7 @@ public:
     int tables() const { return T_; }
     int dim() const { return dim_; }
     static constexpr bool sorts_ids = true;             // create_emb sorts a batch's ids (src/dlrmtest.cpp:62-63)
-    static constexpr int counter_stride = 6;
+    static constexpr int counter_stride = DLRM_CACHE_NUM_COUNTERS;
     void restore(std::vector<int> &, int) {}            // pages of the batch are never dropped by its own reclaim
     void flush() { check(dlrm_cache_flush(h_, nullptr), "dlrm_cache_flush"); hip_check(hipDeviceSynchronize(), "sync"); }
     const float *store(int t) const { return static_cast<const float *>(stores_[t]); }
@@ -189,18 +191,18 @@ private:
         dlrm_cache_state_t st;
         check(dlrm_cache_state(h_, &st, nullptr), "dlrm_cache_state");
         page_count = (int)st.page_count;
-        std::vector<int64_t> c((size_t)T_ * 6);
+        std::vector<int64_t> c((size_t)T_ * counter_stride);
         check(dlrm_cache_counters(h_, c.data(), 0, nullptr), "dlrm_cache_counters");
         for (int t = 0; t < T_; t++) {
-            write_buf[t].read_page_count = (int)(c[t * 6 + 0] - read_base_[t]);
-            write_buf[t].write_page_count = (int)(c[t * 6 + 1] - write_base_[t]);
+            write_buf[t].read_page_count = (int)(c[t * counter_stride + 0] - read_base_[t]);
+            write_buf[t].write_page_count = (int)(c[t * counter_stride + 1] - write_base_[t]);
         }
         last_ = c;
     }
     void reset_one(int i, bool read) {
         if (last_.empty()) refresh();
-        if (read) { read_base_[i] = last_[i * 6 + 0]; write_buf[i].read_page_count = 0; }
-        else { write_base_[i] = last_[i * 6 + 1]; write_buf[i].write_page_count = 0; }
+        if (read) { read_base_[i] = last_[i * counter_stride + 0]; write_buf[i].read_page_count = 0; }
+        else { write_base_[i] = last_[i * counter_stride + 1]; write_buf[i].write_page_count = 0; }
     }
 
     dlrm_cache *h_ = nullptr;

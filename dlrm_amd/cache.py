@@ -29,6 +29,8 @@ class CacheConfig(C.Structure):
         ("h_table_store", C.POINTER(C.c_void_p)),
         ("num_slots", C.c_int64), ("cache_size", C.c_int64),
         ("d_slot_pool", C.c_void_p),
+        ("max_lookup_ids", C.c_int64),
+        ("writeback_dirty_only", C.c_int32),
     ]
 
 
@@ -37,12 +39,15 @@ class CacheState(C.Structure):
                                          "last_lookup_pages_read", "total_pages", "num_slots")]
 
 
-COUNTER_NAMES = ("read", "write", "hit", "miss", "evicted", "resident")
+COUNTER_NAMES = ("read", "write", "hit", "miss", "evicted", "resident", "written_back")
 
 
 class EmbeddingCache:
     def __init__(self, table_rows, dim, cache_size, num_slots, rows_per_page=None, evict_group=8,
-                 row_dtype=torch.float32, device="cuda"):
+                 row_dtype=torch.float32, device="cuda", dirty_only=False, max_lookup_ids=0):
+        """dirty_only: evicted pages are copied back to the store only when mark_dirty() has flagged them
+        (the reference writes every victim back).  max_lookup_ids: most ids one get_emb_vectors call carries;
+        every buffer is then allocated here and no later call allocates."""
         self.L = _capi.lib()
         self.L.dlrm_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.L.dlrm_host_free.argtypes = [C.c_void_p]
@@ -73,6 +78,7 @@ class EmbeddingCache:
         cfg.h_table_store = self._store_arr
         cfg.num_slots, cfg.cache_size = num_slots, cache_size
         cfg.d_slot_pool = self.pool.data_ptr()
+        cfg.max_lookup_ids, cfg.writeback_dirty_only = int(max_lookup_ids), int(bool(dirty_only))
         self.h = C.c_void_p()
         check(self.L.dlrm_cache_create(C.byref(cfg), C.byref(self.h)))
 
@@ -123,6 +129,21 @@ class EmbeddingCache:
     def reclaim(self):
         self.reclaim_finish()           # a pending first half belongs to an earlier step
         check(self.L.dlrm_cache_reclaim(self.h, self._stream()))
+
+    def reclaim_table(self, table):
+        """cache::Reclaim_vector_page(table_ID): the evict_group least recently used pages of one table leave."""
+        self.reclaim_finish()
+        check(self.L.dlrm_cache_reclaim_table(self.h, int(table), self._stream()))
+
+    def set_protect_age(self, age):
+        """Pages used in the last `age` lookup calls are never evicted by the reclaims that follow."""
+        check(self.L.dlrm_cache_set_protect_age(self.h, int(age)))
+
+    def mark_dirty(self, rows):
+        """rows: what get_emb_vectors returned for ids whose rows are about to be updated."""
+        dt = _capi.I32 if rows.dtype == torch.int32 else _capi.I64
+        check(self.L.dlrm_cache_mark_dirty(self.h, C.c_void_p(rows.data_ptr()), dt, C.c_int64(rows.numel()),
+                                           self._stream()))
 
     def reclaim_begin(self):
         """First half of reclaim (choice of victims + asynchronous read-back of their count)."""

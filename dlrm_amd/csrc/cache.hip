@@ -38,8 +38,10 @@ constexpr int kCacheThreads = 256;
 // and starve the kernels of another stream (a prefetching lookup runs beside the MLP).  128 K lanes in
 // flight keep the link busy and leave most wave slots free.
 constexpr int kLinkBlocks = 512;
-constexpr int kNumCounters = 6;  // read_pages, write_pages, hit_ids, miss_ids, evicted_pages, resident_pages
-enum { C_READ = 0, C_WRITE = 1, C_HIT = 2, C_MISS = 3, C_EVICT = 4, C_RESIDENT = 5 };
+constexpr int kNumCounters = DLRM_CACHE_NUM_COUNTERS;  // read_pages, write_pages, hit_ids, miss_ids, evicted_pages,
+                                                       // resident_pages, pages copied back to the store
+enum { C_READ = 0, C_WRITE = 1, C_HIT = 2, C_MISS = 3, C_EVICT = 4, C_RESIDENT = 5, C_WRITTEN_BACK = 6 };
+static_assert(kNumCounters == 7, "counter layout");
 enum { S_HEAD = 0, S_TAIL, S_PAGE_COUNT, S_CACHE_SIZE, S_N_MISS, S_N_CAND, S_ERROR, S_EPOCH, S_PASSES, S_N_ASSIGNED,
        S_COUNT };
 enum { ERR_BAD_ID = 1, ERR_POOL_EXHAUSTED = 2, ERR_EVICTED_CURRENT = 4 };
@@ -64,6 +66,8 @@ struct CacheDev {
     int32_t *page_map;
     int32_t *slot_gp;
     uint32_t *slot_epoch;
+    uint8_t *slot_dirty;   // rows of the slot were updated since it was filled / last written back
+    int dirty_only;        // 1: only dirty pages are copied back to the store; 0: every victim (the reference)
     int32_t *ring;
     int64_t *scalars;
     int64_t *counters;   // [T][kNumCounters]
@@ -91,6 +95,8 @@ struct dlrm_cache {
     hipEvent_t reclaim_ev;   // recorded behind that copy
     bool reclaim_pending;
     bool owns_pool;
+    int protect_age;         // pages used in the last protect_age lookup calls are never victims
+    int reclaim_table;       // table of a pending single-table reclaim, -1 = every table
 };
 
 namespace dlrm {
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(kCacheThreads) void assign_kernel(TableGeom g, Cach
                 d.page_map[gp] = s;
                 d.slot_gp[s] = (int32_t)gp;
                 d.slot_epoch[s] = epoch;
+                d.slot_dirty[s] = 0;
                 placed = true;
             } else {
                 d.page_map[gp] = -1;
@@ -276,15 +283,16 @@ __global__ void finish_lookup_kernel(CacheDev d) {
 
 // reclaim_emb_cache (src/dlrmtest.cpp:397-403): while (page_count > cache_size) one
 // Reclaim_vector_page per table; each drops ws pages (emb_cache.cpp:223-238, :312)
-__global__ void plan_reclaim_kernel(TableGeom g, CacheDev d) {
+// only_table >= 0: one Reclaim_vector_page(only_table) call, whatever page_count is (include/data.h:267)
+__global__ void plan_reclaim_kernel(TableGeom g, CacheDev d, int only_table) {
     const int64_t pc = d.scalars[S_PAGE_COUNT], cs = d.scalars[S_CACHE_SIZE];
     const int64_t per_pass = (int64_t)g.T * g.ws;
-    const int64_t passes = pc > cs ? (pc - cs + per_pass - 1) / per_pass : 0;
+    const int64_t passes = only_table >= 0 ? 1 : (pc > cs ? (pc - cs + per_pass - 1) / per_pass : 0);
     d.scalars[S_PASSES] = passes;
     d.scalars[S_N_CAND] = 0;
     for (int t = 0; t < g.T; t++) {
         const int64_t res = d.counters[t * kNumCounters + C_RESIDENT];
-        const int64_t want = passes * g.ws;
+        const int64_t want = (only_table >= 0 && t != only_table) ? 0 : passes * g.ws;
         d.k_t[t] = want < res ? want : res;
     }
 }
@@ -313,22 +321,46 @@ __global__ __launch_bounds__(kCacheThreads) void age_hist_kernel(TableGeom g, Ca
         if (h[i]) atomicAdd(&d.hist[i], h[i]);
 }
 
-// per table: the youngest age a* such that the pages of age >= a* number at least k_t
-__global__ void threshold_kernel(TableGeom g, CacheDev d) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= g.T) return;
-    int thr = kAgeBins;  // nothing to evict
-    const int64_t k = d.scalars[S_PASSES] == 0 ? 0 : d.k_t[t];
-    if (k > 0) {
-        int64_t cum = 0;
-        for (int a = kAgeBins - 1; a >= 0; a--) {
-            cum += d.hist[t * kAgeBins + a];
-            if (cum >= k) { thr = a; break; }
-        }
-        if (thr == kAgeBins) thr = 0;
+// per table (one workgroup each): the youngest age a* >= protect such that the pages of age >= a* number at
+// least k_t.  Pages younger than `protect` lookup calls are never victims; when fewer than k_t older pages
+// exist, k_t shrinks to what there is.  Thread c owns the bins [4c, 4c+4).
+__global__ __launch_bounds__(kAgeBins / 4) void threshold_kernel(TableGeom g, CacheDev d, int protect) {
+    __shared__ unsigned tot[kAgeBins / 4];
+    __shared__ int thr_s;
+    __shared__ long long k_s;
+    const int t = blockIdx.x, c = threadIdx.x;
+    unsigned b[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a = 4 * c + j;
+        b[j] = a >= protect ? d.hist[t * kAgeBins + a] : 0u;
+        d.hist[t * kAgeBins + a] = 0;
     }
-    d.thr_age[t] = thr;
-    for (int a = 0; a < kAgeBins; a++) d.hist[t * kAgeBins + a] = 0;
+    tot[c] = b[0] + b[1] + b[2] + b[3];
+    if (c == 0) { thr_s = kAgeBins; k_s = 0; }
+    __syncthreads();
+    const int64_t k = d.scalars[S_PASSES] == 0 ? 0 : d.k_t[t];
+    int64_t above = 0;   // pages in bins beyond this thread's
+    for (int cc = c + 1; cc < kAgeBins / 4; cc++) above += tot[cc];
+    if (k > 0) {
+        if (above < k && above + tot[c] >= k) {   // the threshold lies in this thread's bins
+            int64_t cum = above;
+            for (int j = 3; j >= 0; j--) {
+                cum += b[j];
+                if (cum >= k) { thr_s = 4 * c + j; break; }
+            }
+            k_s = k;
+        }
+        if (c == 0 && above + tot[0] < k) {       // fewer evictable pages than wanted: take them all
+            k_s = above + tot[0];
+            thr_s = k_s > 0 ? (protect > 0 ? protect : 0) : kAgeBins;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        d.thr_age[t] = thr_s;
+        d.k_t[t] = k_s;
+    }
 }
 
 __global__ __launch_bounds__(kCacheThreads) void collect_candidates_kernel(TableGeom g, CacheDev d) {
@@ -350,7 +382,10 @@ __global__ __launch_bounds__(kCacheThreads) void collect_candidates_kernel(Table
         }
         const int64_t pos = wave_append(&d.scalars[S_N_CAND], take);
         if (take) {
-            d.cand_key[pos] = ((uint64_t)t << 58) | ((uint64_t)(d.slot_epoch[s] & 0x3ffffffu) << 32) | (uint32_t)gp;
+            // ascending key = table, then oldest first (the age saturates at 2^26 - 1 calls), then page id
+            const uint32_t full_age = now - d.slot_epoch[s];
+            const uint32_t inv_age = 0x3ffffffu - (full_age < 0x3ffffffu ? full_age : 0x3ffffffu);
+            d.cand_key[pos] = ((uint64_t)t << 58) | ((uint64_t)inv_age << 32) | (uint32_t)gp;
             d.cand_val[pos] = (int32_t)s;
         }
     }
@@ -404,12 +439,13 @@ __global__ __launch_bounds__(kCacheThreads) void writeback_victims_kernel(TableG
          w += (int64_t)gridDim.x * kCacheThreads) {
         const int64_t i = w / chunks, c = w - i * chunks;
         if (cand_pos[i] < 0) continue;
+        const int32_t s = d.cand_val_sorted[i];
+        if (d.dirty_only && !d.slot_dirty[s]) continue;   // the store already holds these rows
         const uint64_t key = d.cand_key_sorted[i];
         const int t = (int)(key >> 58);
         const int64_t gp = (int64_t)(uint32_t)key;
         const int64_t page = gp - g.page_base[t];
         if (c * 16 < valid_page_bytes(g, t, page)) {
-            const int32_t s = d.cand_val_sorted[i];
             const uint4 v = *reinterpret_cast<const uint4 *>(d.data + (int64_t)s * g.page_bytes + c * 16);
             *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) = v;
         }
@@ -420,23 +456,31 @@ __global__ __launch_bounds__(kCacheThreads) void evict_kernel(TableGeom g, Cache
                                                                const int32_t *cand_pos) {
     const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
     const int64_t tail = d.scalars[S_TAIL];
-    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n_cand;
-         i += (int64_t)gridDim.x * kCacheThreads) {
-        const int64_t pos = cand_pos[i];
-        if (pos < 0) continue;
-        const uint64_t key = d.cand_key_sorted[i];
-        const int32_t s = d.cand_val_sorted[i];
-        const int64_t gp = (int64_t)(uint32_t)key;
-        // a page used by the current call is being dropped: the caller's row indices into the
-        // slot pool go stale (the reference would crash in save_emb on the freed page)
-        if (d.slot_epoch[s] == now) atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_EVICTED_CURRENT);
-        d.ring[(tail + pos) % d.S] = s;
-        d.page_map[gp] = -1;
-        d.slot_gp[s] = -1;
+    // every lane of a wave makes the same number of trips (wave_add2 ballots)
+    for (int64_t base = (int64_t)blockIdx.x * kCacheThreads; base < n_cand; base += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t pos = i < n_cand ? cand_pos[i] : -1;
+        bool victim = pos >= 0, written = false;
+        int t = 0;
+        if (victim) {
+            const uint64_t key = d.cand_key_sorted[i];
+            const int32_t s = d.cand_val_sorted[i];
+            const int64_t gp = (int64_t)(uint32_t)key;
+            t = (int)(key >> 58);
+            // a page used by the current call is being dropped: the caller's row indices into the
+            // slot pool go stale (the reference would crash in save_emb on the freed page)
+            if (d.slot_epoch[s] == now) atomicOr((unsigned long long *)&d.scalars[S_ERROR], (unsigned long long)ERR_EVICTED_CURRENT);
+            written = !d.dirty_only || d.slot_dirty[s];
+            d.slot_dirty[s] = 0;
+            d.ring[(tail + pos) % d.S] = s;
+            d.page_map[gp] = -1;
+            d.slot_gp[s] = -1;
+        }
+        wave_add2(d.counters, victim, t, C_WRITTEN_BACK, written, C_WRITTEN_BACK, false);
     }
 }
 
-__global__ void finish_reclaim_kernel(TableGeom g, CacheDev d) {
+__global__ void finish_reclaim_kernel(TableGeom g, CacheDev d, int only_table) {
     const int64_t passes = d.scalars[S_PASSES];
     int64_t freed = 0;
     for (int t = 0; t < g.T; t++) {
@@ -444,11 +488,22 @@ __global__ void finish_reclaim_kernel(TableGeom g, CacheDev d) {
         freed += k;
         d.counters[t * kNumCounters + C_EVICT] += k;
         d.counters[t * kNumCounters + C_RESIDENT] -= k;
-        d.counters[t * kNumCounters + C_WRITE] += passes * g.ws;   // write_page_count += ws_opt per call (:315)
+        if (only_table < 0 || t == only_table) {
+            d.counters[t * kNumCounters + C_WRITE] += passes * g.ws;   // write_page_count += ws_opt per call (:315)
+            d.scalars[S_PAGE_COUNT] -= passes * g.ws;                   // page_count -= ws_opt per call (:312)
+        }
     }
     d.scalars[S_TAIL] += freed;
-    d.scalars[S_PAGE_COUNT] -= passes * g.T * g.ws;               // page_count -= ws_opt per call (:312)
     d.scalars[S_PASSES] = 0;
+}
+
+// rows of the slot pool that a training step updates: their pages differ from the store from now on
+template <typename IDX>
+__global__ __launch_bounds__(kCacheThreads) void mark_dirty_kernel(CacheDev d, int vpo, const IDX *rows, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t r = (int64_t)rows[i];
+        if (r >= 0 && r / vpo < d.S) d.slot_dirty[r / vpo] = 1;
+    }
 }
 
 __global__ __launch_bounds__(kCacheThreads) void flush_kernel(TableGeom g, CacheDev d) {
@@ -459,6 +514,7 @@ __global__ __launch_bounds__(kCacheThreads) void flush_kernel(TableGeom g, Cache
         const int64_t s = w / chunks, c = w - s * chunks;
         const int32_t gp = d.slot_gp[s];
         if (gp < 0) continue;
+        if (d.dirty_only && !d.slot_dirty[s]) continue;
         const int t = table_of_page(g, gp);
         const int64_t page = gp - g.page_base[t];
         if (c * 16 < valid_page_bytes(g, t, page)) {
@@ -468,11 +524,17 @@ __global__ __launch_bounds__(kCacheThreads) void flush_kernel(TableGeom g, Cache
     }
 }
 
+__global__ void clear_dirty_kernel(CacheDev d) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < d.S; s += (int64_t)gridDim.x * blockDim.x)
+        d.slot_dirty[s] = 0;
+}
+
 __global__ void init_ring_kernel(CacheDev d) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.S; i += (int64_t)gridDim.x * blockDim.x) {
         d.ring[i] = (int32_t)i;
         d.slot_gp[i] = -1;
         d.slot_epoch[i] = 0;
+        d.slot_dirty[i] = 0;
     }
 }
 
@@ -505,6 +567,26 @@ extern "C" int dlrm_host_alloc(void **h_ptr, size_t bytes) {
 
 extern "C" int dlrm_host_free(void *h_ptr) {
     if (h_ptr) DLRM_HIP(hipHostFree(h_ptr));
+    return DLRM_OK;
+}
+
+static int ensure_lookup_buffers(dlrm_cache *c, int64_t n) {
+    if (n <= c->miss_cap) return DLRM_OK;
+    (void)hipFree(c->d.miss); (void)hipFree(c->d.miss_sorted);
+    c->d.miss = c->d.miss_sorted = nullptr;
+    c->miss_cap = 0;
+    if (int rc = dev_alloc(&c->d.miss, (size_t)n)) return rc;
+    if (int rc = dev_alloc(&c->d.miss_sorted, (size_t)n)) return rc;
+    c->miss_cap = n;
+    return DLRM_OK;
+}
+
+static int ensure_sort_tmp(dlrm_cache *c, size_t bytes) {
+    if (bytes <= c->sort_tmp_bytes) return DLRM_OK;
+    (void)hipFree(c->sort_tmp);
+    c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+    DLRM_HIP(hipMalloc(&c->sort_tmp, bytes));
+    c->sort_tmp_bytes = bytes;
     return DLRM_OK;
 }
 
@@ -549,10 +631,13 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
     }
     CacheDev &d = c->d;
     d.S = cfg->num_slots;
+    d.dirty_only = cfg->writeback_dirty_only ? 1 : 0;
+    c->reclaim_table = -1;
     int rc = DLRM_OK;
     if (!rc) rc = dev_alloc(&d.page_map, (size_t)c->total_pages);
     if (!rc) rc = dev_alloc(&d.slot_gp, (size_t)d.S);
     if (!rc) rc = dev_alloc(&d.slot_epoch, (size_t)d.S);
+    if (!rc) rc = dev_alloc(&d.slot_dirty, (size_t)d.S);
     if (!rc) rc = dev_alloc(&d.ring, (size_t)d.S);
     if (!rc) rc = dev_alloc(&d.scalars, (size_t)S_COUNT);
     if (!rc) rc = dev_alloc(&d.counters, (size_t)g.T * kNumCounters);
@@ -575,6 +660,18 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
         rc = set_error(DLRM_ERR_NOMEM, "reclaim staging allocation failed");
     if (!rc && hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), sizeof(int64_t) * S_COUNT, 0) != hipSuccess)
         rc = set_error(DLRM_ERR_NOMEM, "hipHostMalloc failed");
+    if (!rc && cfg->max_lookup_ids > 0) {
+        // everything a lookup of up to max_lookup_ids ids and a reclaim can need, so that no later call allocates
+        rc = ensure_lookup_buffers(c, cfg->max_lookup_ids);
+        size_t t1 = 0, t2 = 0;
+        if (!rc && rocprim::radix_sort_keys(nullptr, t1, d.miss, d.miss_sorted, (size_t)cfg->max_lookup_ids, 0u, 31u,
+                                            (hipStream_t) nullptr, false) != hipSuccess)
+            rc = set_error(DLRM_ERR_HIP, "radix sort size query failed");
+        if (!rc && rocprim::radix_sort_pairs(nullptr, t2, d.cand_key, d.cand_key_sorted, d.cand_val, d.cand_val_sorted,
+                                             (size_t)d.S, 0u, 64u, (hipStream_t) nullptr, false) != hipSuccess)
+            rc = set_error(DLRM_ERR_HIP, "radix sort size query failed");
+        if (!rc) rc = ensure_sort_tmp(c, t1 > t2 ? t1 : t2);
+    }
     if (rc) { dlrm_cache_destroy(c); return rc; }
     (void)hipMemset(d.page_map, 0xff, sizeof(int32_t) * (size_t)c->total_pages);
     (void)hipMemset(d.scalars, 0, sizeof(int64_t) * S_COUNT);
@@ -596,7 +693,7 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
 extern "C" int dlrm_cache_destroy(dlrm_cache *c) {
     if (!c) return DLRM_OK;
     CacheDev &d = c->d;
-    (void)hipFree(d.page_map); (void)hipFree(d.slot_gp); (void)hipFree(d.slot_epoch); (void)hipFree(d.ring); (void)hipFree(d.scalars);
+    (void)hipFree(d.page_map); (void)hipFree(d.slot_gp); (void)hipFree(d.slot_epoch); (void)hipFree(d.slot_dirty); (void)hipFree(d.ring); (void)hipFree(d.scalars);
     (void)hipFree(d.counters); (void)hipFree(d.k_t); (void)hipFree(d.thr_age); (void)hipFree(d.hist); (void)hipFree(d.miss); (void)hipFree(d.miss_sorted);
     (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted); (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
     if (c->owns_pool) (void)hipFree(d.data);
@@ -612,26 +709,6 @@ extern "C" int dlrm_cache_storage(dlrm_cache *c, void **d_data, int64_t *total_r
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
     if (d_data) *d_data = c->d.data;
     if (total_rows) *total_rows = c->d.S * c->g.vpo;
-    return DLRM_OK;
-}
-
-static int ensure_lookup_buffers(dlrm_cache *c, int64_t n) {
-    if (n <= c->miss_cap) return DLRM_OK;
-    (void)hipFree(c->d.miss); (void)hipFree(c->d.miss_sorted);
-    c->d.miss = c->d.miss_sorted = nullptr;
-    c->miss_cap = 0;
-    if (int rc = dev_alloc(&c->d.miss, (size_t)n)) return rc;
-    if (int rc = dev_alloc(&c->d.miss_sorted, (size_t)n)) return rc;
-    c->miss_cap = n;
-    return DLRM_OK;
-}
-
-static int ensure_sort_tmp(dlrm_cache *c, size_t bytes) {
-    if (bytes <= c->sort_tmp_bytes) return DLRM_OK;
-    (void)hipFree(c->sort_tmp);
-    c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
-    DLRM_HIP(hipMalloc(&c->sort_tmp, bytes));
-    c->sort_tmp_bytes = bytes;
     return DLRM_OK;
 }
 
@@ -686,9 +763,9 @@ extern "C" int dlrm_cache_reclaim_begin(dlrm_cache *c, dlrm_stream_t stream) {
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
     DLRM_REQUIRE(!c->reclaim_pending, "dlrm_cache_reclaim_begin called twice without dlrm_cache_reclaim_finish");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(plan_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(plan_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d, c->reclaim_table);
     hipLaunchKernelGGL(age_hist_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
-    hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(64), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)c->g.T), dim3(kAgeBins / 4), 0, s, c->g, c->d, c->protect_age);
     hipLaunchKernelGGL(collect_candidates_kernel, dim3(grid_for(c->d.S)), dim3(kCacheThreads), 0, s, c->g, c->d);
     DLRM_LAUNCH_CHECK();
     // the candidate count decides the size of the sort: one small read-back, waited for in _finish
@@ -722,7 +799,7 @@ extern "C" int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream) {
         hipLaunchKernelGGL(evict_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
     }
-    hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d);
+    hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d, c->reclaim_table);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -732,9 +809,45 @@ extern "C" int dlrm_cache_reclaim(dlrm_cache *c, dlrm_stream_t stream) {
     return dlrm_cache_reclaim_finish(c, stream);
 }
 
+extern "C" int dlrm_cache_reclaim_table(dlrm_cache *c, int32_t table, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(table >= 0 && table < c->g.T, "table %d out of range", table);
+    DLRM_REQUIRE(!c->reclaim_pending, "a reclaim is pending: call dlrm_cache_reclaim_finish first");
+    c->reclaim_table = table;
+    int rc = dlrm_cache_reclaim_begin(c, stream);
+    if (!rc) rc = dlrm_cache_reclaim_finish(c, stream);
+    c->reclaim_table = -1;
+    return rc;
+}
+
+extern "C" int dlrm_cache_set_protect_age(dlrm_cache *c, int32_t age) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(age >= 0 && age < kAgeBins, "protect age must be 0..%d", kAgeBins - 1);
+    c->protect_age = age;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_mark_dirty(dlrm_cache *c, const void *d_rows, int32_t idx_dtype, int64_t n, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(idx_dtype == DLRM_I32 || idx_dtype == DLRM_I64, "idx_dtype %d", idx_dtype);
+    DLRM_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_rows != nullptr, "d_rows is NULL");
+    hipStream_t s = as_stream(stream);
+    if (idx_dtype == DLRM_I64)
+        hipLaunchKernelGGL(mark_dirty_kernel<int64_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->d, c->g.vpo,
+                           static_cast<const int64_t *>(d_rows), n);
+    else
+        hipLaunchKernelGGL(mark_dirty_kernel<int32_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->d, c->g.vpo,
+                           static_cast<const int32_t *>(d_rows), n);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream) {
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
     hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(kCacheThreads), 0, as_stream(stream), c->g, c->d);
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3(grid_for(c->d.S)), dim3(256), 0, as_stream(stream), c->d);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

@@ -255,8 +255,11 @@ class DLRM:
                 cache_pages = max(int(pages * cache_fraction), 1)
                 # a lookup can bring in one page per id of the global batch on top of the capacity
                 headroom = min(pages, self.Tl * self.Bg * cfg.lookups)
+                # only updated pages are copied back on eviction (inference costs no device-to-host traffic);
+                # every buffer of a lookup / reclaim is allocated now (ragged batches: up to twice the nominal ids)
                 self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
-                                            row_dtype=wdtype, device=dev)
+                                            row_dtype=wdtype, device=dev, dirty_only=True,
+                                            max_lookup_ids=2 * max(self.Tl * self.Bg * cfg.lookups, 1))
                 if init_tables:
                     self.cache.write(seed, table_ids=self.local_table_ids)
             else:
@@ -373,9 +376,13 @@ class DLRM:
             raise ValueError("ragged batches need table_pos (where each table's ids start)")
         return [t * (n // self.Tl) for t in range(self.Tl + 1)]
 
-    def lookup(self, indices, table_pos=None):
-        """create_emb's gather (src/dlrmtest.cpp:53-86): slot-pool row of every id of the batch."""
-        return self.cache.get_emb_vectors(indices, self._table_pos(indices, table_pos))
+    def lookup(self, indices, table_pos=None, train=True):
+        """create_emb's gather (src/dlrmtest.cpp:53-86): slot-pool row of every id of the batch.  train: the
+        rows will be updated, so their pages must be copied back when they leave the cache."""
+        rows = self.cache.get_emb_vectors(indices, self._table_pos(indices, table_pos))
+        if train and self.cache_policy == "lru":
+            self.cache.mark_dirty(rows)
+        return rows
 
     def _pipeline_next(self, next_indices, next_table_pos):
         """Cache work that runs beside this step's kernels, on the lookup stream: the second half of the
@@ -390,6 +397,10 @@ class DLRM:
             ev.record()
             self._rows = (next_indices, rows, ev)
             self.lookup_stream.wait_stream(main)        # this step's rows are updated
+            # the reference reclaims BEFORE it looks the next batch up (src/dlrmtest.cpp:484-494); here the
+            # order is reversed, so the pages of the batch just looked up (age 0) must not be victims: the
+            # next step pools from them while the second half of this reclaim runs
+            self.cache.set_protect_age(1)
             self.cache.reclaim_begin()
 
     def _rw_kwargs(self, indices, offsets):
@@ -686,8 +697,23 @@ class DLRM:
         self.x_dense[:, :self.cfg.dense_in].copy_(dense)
         self.labels.copy_(labels.reshape(-1))
 
-    def forward(self, indices, offsets):
-        """Inference: Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward."""
+    def forward(self, indices, offsets, table_pos=None):
+        """Inference: Net2::forward (src/dlrmtest.cpp:254-272) around emb::forward.  Cached tables (page-LRU
+        policy): ids are looked up first, nothing is marked for write-back, the cache is reclaimed afterwards."""
+        if self.cache is not None:
+            if self.cache_policy != "lru":
+                raise ValueError("inference through the cache is offered for the page-LRU policy")
+            main = torch.cuda.current_stream()
+            self.lookup_stream.wait_stream(main)
+            with torch.cuda.stream(self.lookup_stream):
+                self.cache.reclaim_finish()
+                rows = self.lookup(indices, table_pos, train=False)
+            main.wait_stream(self.lookup_stream)
+            rows.record_stream(main)
+            self._rows = None
+            self._run_items(self._forward_items(rows, offsets))
+            self._reclaim_now()
+            return self.pred
         self._run_items(self._forward_items(indices, offsets))
         return self.pred
 
@@ -742,8 +768,13 @@ class DLRM:
             if pipelined:
                 self._pipeline_next(next_indices, next_table_pos)
             else:
-                self.lookup_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.lookup_stream):
-                    self.cache.reclaim()
-                torch.cuda.current_stream().wait_stream(self.lookup_stream)
+                self._reclaim_now()
         return self.loss
+
+    def _reclaim_now(self):
+        """reclaim_emb_cache in the reference's place: after the batch's rows are done with, any page may go."""
+        self.lookup_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.lookup_stream):
+            self.cache.set_protect_age(0)
+            self.cache.reclaim()
+        torch.cuda.current_stream().wait_stream(self.lookup_stream)

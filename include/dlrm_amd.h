@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1007
+#define DLRM_ABI_VERSION 1008
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -332,6 +332,15 @@ typedef struct dlrm_cache_config {
     int64_t cache_size;          /* cache::cache_size: reclaim brings page_count down to at most this */
     void *d_slot_pool;           /* optional caller-owned HBM for the slots, num_slots*rows_per_page*dim */
                                  /* elements, 16-byte aligned; NULL = the cache allocates it */
+    int64_t max_lookup_ids;      /* most ids one dlrm_cache_lookup call will carry: its buffers and those of a */
+                                 /* reclaim are allocated at create and no later call allocates; 0 = they grow */
+                                 /* on demand (a call may then hipMalloc / hipFree: not while another stream */
+                                 /* still uses the cache) */
+    int32_t writeback_dirty_only; /* 0: every evicted page is copied back to the store, like the reference */
+                                 /* (src/emb_cache.cpp:259-305 has no dirty bit); 1: only pages that */
+                                 /* dlrm_cache_mark_dirty has marked since they were read (inference and */
+                                 /* read-mostly tables then cost no device-to-host traffic).  Residency, */
+                                 /* eviction order and counters 0..5 are the same either way */
 } dlrm_cache_config;
 
 typedef struct dlrm_cache_state_t {
@@ -450,12 +459,35 @@ int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream);
 /* Write every resident page back to the store without dropping it. */
 int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream);
 /*
- * h_out[t*6 + k], k = 0 pages read (write_buffer::read_page_count), 1 pages
+ * cache::Reclaim_vector_page(table_ID) (include/data.h:267, src/emb_cache.cpp:208-316): the evict_group least
+ * recently used pages of ONE table leave, whatever page_count is; page_count -= evict_group and the table's
+ * write_page_count += evict_group as in the reference (:312, :315), also when the table holds fewer pages.
+ * Synchronises like dlrm_cache_reclaim.
+ */
+int dlrm_cache_reclaim_table(dlrm_cache *c, int32_t table, dlrm_stream_t stream);
+/*
+ * Pages whose last use is fewer than `age` lookup calls old are never chosen as victims by the reclaims that
+ * follow; a table with fewer older pages than a reclaim wants gives what it has (page_count and
+ * write_page_count still move by evict_group per pass, the reference's arithmetic).  0 (default) is the
+ * reference: any page may go.  A pipelined host that looks batch n+1 up BEFORE it reclaims for batch n
+ * (the reverse of src/dlrmtest.cpp:484-494) sets 1: the rows batch n+1 will pool from must stay.
+ */
+int dlrm_cache_set_protect_age(dlrm_cache *c, int32_t age);
+/*
+ * The slot-pool rows d_rows[0..n) (what dlrm_cache_lookup returned; negative entries are skipped) are about to
+ * be updated: their pages will be copied back when they leave the cache.  Stands in for the reference's
+ * unconditional write-back of every evicted page; only looked at when writeback_dirty_only is set.
+ */
+int dlrm_cache_mark_dirty(dlrm_cache *c, const void *d_rows, int32_t idx_dtype, int64_t n, dlrm_stream_t stream);
+/*
+ * h_out[t*DLRM_CACHE_NUM_COUNTERS + k], k = 0 pages read (write_buffer::read_page_count), 1 pages
  * written (write_page_count, advances by evict_group per table per pass as in
  * src/emb_cache.cpp:315), 2 ids that hit, 3 ids that missed, 4 pages evicted,
- * 5 pages resident.  reset_read_write zeroes k = 0,1 afterwards
+ * 5 pages resident, 6 pages copied back to the store on eviction (= k 4 unless writeback_dirty_only).
+ * reset_read_write zeroes k = 0,1 afterwards
  * (cache::read_page / write_page, include/data.h:274-285).  Synchronises.
  */
+#define DLRM_CACHE_NUM_COUNTERS 7
 int dlrm_cache_counters(dlrm_cache *c, int64_t *h_out, int32_t reset_read_write, dlrm_stream_t stream);
 int dlrm_cache_state(dlrm_cache *c, dlrm_cache_state_t *h_state, dlrm_stream_t stream);
 /* cache_size = v (the reference freezes it to page_count, src/dlrmtest.cpp:496-498). */

@@ -417,6 +417,13 @@ typedef struct orc_pagecache {
     int64_t n_slots;
     int64_t *ring;
     int64_t ring_head, ring_tail; /* monotonically increasing; index mod n_slots */
+    /* Write-back economy (not in the reference, which writes every victim back, emb_cache.cpp:259-305):
+     * a page is dirty from the first update of one of its rows (orc_pagecache_mark_dirty) until it leaves;
+     * written_back counts the victims that have to be copied to the store: all of them, or with dirty_only
+     * the dirty ones. */
+    unsigned char *dirty; /* [num_tables * pages_per_table] */
+    int64_t *written_back;
+    int dirty_only;
 } orc_pagecache;
 
 orc_pagecache *orc_pagecache_create(int num_tables, int64_t rows_per_table, int dim, int page_bytes,
@@ -440,6 +447,8 @@ orc_pagecache *orc_pagecache_create(int num_tables, int64_t rows_per_table, int 
     c->write_pages = (int64_t *)calloc(num_tables, sizeof(int64_t));
     c->hit_ids = (int64_t *)calloc(num_tables, sizeof(int64_t));
     c->miss_ids = (int64_t *)calloc(num_tables, sizeof(int64_t));
+    c->written_back = (int64_t *)calloc(num_tables, sizeof(int64_t));
+    c->dirty = (unsigned char *)calloc((size_t)n, 1);
     return c;
 }
 
@@ -447,7 +456,7 @@ void orc_pagecache_destroy(orc_pagecache *c) {
     if (!c) return;
     free(c->nodes); free(c->head); free(c->tail); free(c->lru_len);
     free(c->read_pages); free(c->write_pages); free(c->hit_ids); free(c->miss_ids);
-    free(c->ring);
+    free(c->ring); free(c->dirty); free(c->written_back);
     free(c);
 }
 
@@ -528,6 +537,11 @@ int orc_pagecache_reclaim_table(orc_pagecache *c, int t, int64_t *evicted_out) {
         pc_unlink(c, t, page);
         nd[page].prev = -2;
         nd[page].next = -1;
+        {
+            unsigned char *dy = c->dirty + (int64_t)t * c->pages_per_table + page;
+            if (!c->dirty_only || *dy) c->written_back[t]++;
+            *dy = 0;
+        }
         if (c->n_slots > 0) {
             c->ring[(c->ring_tail++) % c->n_slots] = nd[page].slot;
             nd[page].slot = -1;
@@ -586,11 +600,21 @@ int64_t orc_pagecache_lru_order(const orc_pagecache *c, int t, int64_t *out, int
     return k;
 }
 
-/* counters: which 0 read_pages, 1 write_pages, 2 hit_ids, 3 miss_ids;
+void orc_pagecache_set_dirty_only(orc_pagecache *c, int on) { c->dirty_only = on; }
+/* rows `ids` of table t are updated: their (resident) pages differ from the store from now on */
+void orc_pagecache_mark_dirty(orc_pagecache *c, int t, const int64_t *ids, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        int64_t page = ids[i] / c->vpo;
+        if (c->nodes[(int64_t)t * c->pages_per_table + page].prev != -2)
+            c->dirty[(int64_t)t * c->pages_per_table + page] = 1;
+    }
+}
+
+/* counters: which 0 read_pages, 1 write_pages, 2 hit_ids, 3 miss_ids, 4 written_back;
  * reset != 0 zeroes them after the copy (cache::read_page / write_page,
  * include/data.h:274-285) */
 void orc_pagecache_counters(orc_pagecache *c, int which, int64_t *out, int reset) {
     int64_t *src = which == 0 ? c->read_pages : which == 1 ? c->write_pages
-                 : which == 2 ? c->hit_ids : c->miss_ids;
+                 : which == 2 ? c->hit_ids : which == 3 ? c->miss_ids : c->written_back;
     for (int t = 0; t < c->num_tables; t++) { out[t] = src[t]; if (reset) src[t] = 0; }
 }

@@ -213,6 +213,13 @@ class PageCache:
     def reclaim(self):
         return self.L.orc_pagecache_reclaim(self.h)
 
+    def set_dirty_only(self, on=True):
+        self.L.orc_pagecache_set_dirty_only(self.h, int(on))
+
+    def mark_dirty(self, table, ids):
+        ids = _i64(ids)
+        self.L.orc_pagecache_mark_dirty(self.h, table, _p(ids), C.c_int64(ids.size))
+
     def reclaim_table(self, table):
         ev = np.empty(64, dtype=np.int64)
         k = self.L.orc_pagecache_reclaim_table(self.h, table, _p(ev))
@@ -232,7 +239,8 @@ class PageCache:
 
     def counters(self, which, reset=False):
         out = np.zeros(self.T, dtype=np.int64)
-        self.L.orc_pagecache_counters(self.h, {"read": 0, "write": 1, "hit": 2, "miss": 3}[which], _p(out), int(reset))
+        self.L.orc_pagecache_counters(self.h, {"read": 0, "write": 1, "hit": 2, "miss": 3, "written_back": 4}[which],
+                                      _p(out), int(reset))
         return out
 
     def lru_order(self, table):

@@ -150,3 +150,65 @@ def test_store_image_roundtrip_through_the_cache(tmp_path):
     exp0[[5, 200, 299]] += 1.0
     assert np.array_equal(back[0], exp0) and np.array_equal(back[1], tables[1])
     c.close()
+
+
+def test_reclaim_of_one_table_matches_oracle(oracle):
+    """cache::Reclaim_vector_page(table_ID) (include/data.h:267): the ws_opt least recently used pages of one table
+    leave, page_count and that table's write counter move by ws_opt -- also when the table holds fewer pages."""
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(9)
+    rows, dim, T = [800, 40, 3000], 32, 3
+    cache = EmbeddingCache(rows, dim, cache_size=10 ** 6, num_slots=600, rows_per_page=4, evict_group=8)
+    cache.write(seed=2)
+    pc = oracle.PageCache(T, max(rows), dim, cache_size=10 ** 6, page_bytes=4 * dim * 4, ws_opt=8, n_slots=600)
+    for step in range(10):
+        ids, offs = sorted_batch(rng, rows, [int(x) for x in rng.integers(1, 60, size=T)])
+        cache.get_emb_vectors(torch.from_numpy(ids).cuda(), offs)
+        for t in range(T):
+            pc.get(t, ids[offs[t]:offs[t + 1]])
+        for t in ([step % T] if step % 2 else [1, 1, (step + 1) % T]):     # table 1 (10 pages) runs dry
+            cache.reclaim_table(t)
+            pc.reclaim_table(t)
+            compare_state(cache, pc, T)
+    assert cache.counters()["evicted"].sum() > 0
+    cache.close()
+
+
+@pytest.mark.parametrize("vpo", [1, 8])
+def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo):
+    """writeback_dirty_only: residency, eviction order and the reference's counters are unchanged; only pages
+    marked dirty since they were read are copied back (counter 6), and the store still ends up with every update."""
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(21 + vpo)
+    rows, dim = [2000, 500, 1500, 64], 16
+    T = len(rows)
+    n_slots, cap, ws = 1500, 300, 8
+    cache = EmbeddingCache(rows, dim, cache_size=cap, num_slots=n_slots, rows_per_page=vpo, evict_group=ws,
+                           dirty_only=True, max_lookup_ids=4 * 200)
+    cache.write(seed=3)
+    pc = oracle.PageCache(T, max(rows), dim, cache_size=cap, page_bytes=vpo * dim * 4, ws_opt=ws, n_slots=n_slots)
+    pc.set_dirty_only(True)
+    expect = [s.copy() for s in cache.store]
+    for step in range(14):
+        ids, offs = sorted_batch(rng, rows, [int(x) for x in rng.integers(1, 200, size=T)])
+        got_rows = cache.get_emb_vectors(torch.from_numpy(ids).cuda(), offs)
+        for t in range(T):
+            pc.get(t, ids[offs[t]:offs[t + 1]])
+        # tables 0 and 2 train (their rows change), 1 and 3 are only read
+        for t in (0, 2):
+            seg = got_rows[offs[t]:offs[t + 1]]
+            cache.mark_dirty(seg)
+            pc.mark_dirty(t, ids[offs[t]:offs[t + 1]])
+            cache.pool[torch.unique(seg.long())] += 1.0
+            expect[t][np.unique(ids[offs[t]:offs[t + 1]])] += 1.0
+        cache.reclaim()
+        pc.reclaim()
+        compare_state(cache, pc, T)
+        assert np.array_equal(cache.counters()["written_back"], pc.counters("written_back"))
+    cnt = cache.counters()
+    assert cnt["written_back"][[1, 3]].sum() == 0 and cnt["evicted"][[1, 3]].sum() > 0   # read-only tables cost nothing
+    assert 0 < cnt["written_back"][[0, 2]].sum() <= cnt["evicted"][[0, 2]].sum()
+    cache.flush()
+    for t in range(T):
+        assert np.array_equal(cache.store[t], expect[t]), "store of table %d" % t
+    cache.close()

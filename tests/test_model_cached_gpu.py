@@ -64,6 +64,80 @@ def test_cached_training_matches_oracle(oracle, rows_per_page, prefetch, kind):
     m.cache.close()
 
 
+@pytest.mark.parametrize("rows_per_page", [1, 8])
+def test_pipelined_training_with_a_cache_smaller_than_one_batch(oracle, rows_per_page):
+    """The pipelined loop looks batch n+1 up before it reclaims for batch n.  With a capacity below one batch's
+    pages every reclaim wants more victims than there are old pages; the pages of the batch just looked up must
+    stay (protect age 1) or the next step would pool from recycled slots.  Zipf ids; losses, predictions and the
+    flushed store against the oracle's step on whole tables."""
+    from dlrm_amd.model import DLRM, DLRMConfig
+    from tests.test_config_shapes_gpu import make_batch_dist
+    cfg = DLRMConfig(table_rows=[20000, 16000, 24000, 20000], dim=16, dense_in=13, bottom=[32, 16], top=[24, 1],
+                     lr=0.05, lookups=4)
+    B, T = 512, 4
+    m = DLRM(cfg, B, seed=5, cache_fraction=0.02 if rows_per_page == 1 else 0.1, cache_rows_per_page=rows_per_page,
+             replay=True)
+    assert m.cache.state().cache_size < 2000          # one batch touches about 3300 / 2700 pages
+    tables = [oracle.table_init_uniform(r * cfg.dim, (5 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+              for t, r in enumerate(cfg.table_rows)]
+    Ws = [w.cpu().numpy().copy() for w in m.bottom.W + m.top.W]
+    bs = [b.cpu().numpy().copy() for b in m.bottom.b + m.top.b]
+    rng = np.random.default_rng(41)
+    n_steps = 8
+    host = [make_batch_dist(rng, cfg, B, "zipf") for _ in range(n_steps)]
+    dev = [(torch.from_numpy(d).cuda(), torch.from_numpy(i.astype(np.int32)).cuda(),
+            torch.from_numpy(o.astype(np.int32)).cuda(), torch.from_numpy(l).cuda()) for d, i, o, l in host]
+    for s in range(n_steps):
+        dense, idx, off, labels = host[s]
+        m.load_batch(dev[s][0], dev[s][3])
+        loss = m.train_step(dev[s][1], dev[s][2], next_indices=dev[s + 1][1] if s + 1 < n_steps else None)
+        torch.cuda.synchronize()
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                               cfg.lr)
+        assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        assert (m.cache.state().error_flags, int(m.err_flag.item())) == (0, 0), s
+    assert m.cache.counters()["evicted"].sum() > 0
+    m.cache.flush()
+    for t in range(T):
+        assert rel_err(np.asarray(m.cache.store[t]), tables[t]) <= 1e-5
+    m.cache.close()
+
+
+def test_inference_through_the_cache_writes_nothing_back(oracle):
+    """DLRM.forward with cached tables: predictions of the oracle's forward pass; pages come and go but none is
+    copied back to the store (nothing was updated)."""
+    import copy
+    from dlrm_amd.model import DLRM, DLRMConfig
+    from tests.test_config_shapes_gpu import make_batch_dist
+    cfg = DLRMConfig(table_rows=[20000, 16000, 24000, 20000], dim=16, dense_in=13, bottom=[32, 16], top=[24, 1],
+                     lr=0.05, lookups=4)
+    B = 512
+    m = DLRM(cfg, B, seed=5, cache_fraction=0.05, cache_rows_per_page=1)
+    tables = [oracle.table_init_uniform(r * cfg.dim, (5 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+              for t, r in enumerate(cfg.table_rows)]
+    Ws = [w.cpu().numpy().copy() for w in m.bottom.W + m.top.W]
+    bs = [b.cpu().numpy().copy() for b in m.bottom.b + m.top.b]
+    before = [np.asarray(s).copy() for s in m.cache.store]
+    rng = np.random.default_rng(43)
+    for s in range(6):
+        dense, idx, off, labels = make_batch_dist(rng, cfg, B, "zipf")
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        pred = m.forward(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(off.astype(np.int32)).cuda())
+        torch.cuda.synchronize()
+        _, pred_ref = oracle_train_step(oracle, cfg, copy.deepcopy(tables), copy.deepcopy(Ws), copy.deepcopy(bs), dense,
+                                        idx, off, labels, len(cfg.bottom), cfg.lr)
+        assert rel_err(pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        # (flag 4: the reclaim after a batch may drop that batch's own pages -- it is done with them)
+        assert m.cache.state().error_flags & ~4 == 0
+    cnt = m.cache.counters()
+    assert cnt["evicted"].sum() > 0 and cnt["written_back"].sum() == 0
+    m.cache.flush()
+    for a, b in zip(before, m.cache.store):
+        assert np.array_equal(a, np.asarray(b))
+    m.cache.close()
+
+
 @pytest.mark.parametrize("replay", [False, True], ids=["eager", "replay"])
 @pytest.mark.parametrize("kind", ["dot", "cat"])
 def test_training_through_the_vector_cache_matches_oracle(oracle, kind, replay):
