@@ -147,17 +147,20 @@ __device__ inline void load_frag(const float *__restrict__ s, int o_base, int q,
 
 // Epilogue.  Register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile: a row
 // per register, so direct stores would be 4 bytes per lane.  Each wave instead parks 32 rows of its
-// 64x64 block at a time in LDS (`ct`: 4 waves x 32 x 68 floats, the staging buffers are free by
-// now) and streams them out as 16-byte row segments -- 16 lanes per 256-byte row piece -- with
+// (32 MI) x (32 NI) block at a time in LDS (`ct`: 4 waves x 32 x (32 NI + 4) floats, the staging buffers are
+// free by now) and streams them out as 16-byte row segments -- 8 NI lanes per row piece -- with
 // bias / ReLU / mask fused.
-__device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[2][2], float *ct_all, int m0, int n0,
+template <int MI, int NI>
+__device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI][NI], float *ct_all, int m0, int n0,
                                     int bz) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wr = wave >> 1, wc = wave & 1;
     float *C = p.C + (int64_t)bz * p.slab_stride;
-    constexpr int CT_LD = 68;
+    constexpr int CT_LD = 32 * NI + 4;
+    constexpr int LPR = 8 * NI;           // lanes per row piece
+    constexpr int RPI = 64 / LPR;         // rows per iteration
     float *ct = ct_all + wave * (32 * CT_LD);
-    const int cn = n0 + wc * 64 + (lane & 15) * 4;
+    const int cn = n0 + wc * (32 * NI) + (lane % LPR) * 4;
     const bool c_vec = (reinterpret_cast<uintptr_t>(C) % 16 == 0) && (p.ldc % 4 == 0) &&
                        (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -168,19 +171,19 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[2][
         if (cn + 3 < p.N) bv.w = p.bias[cn + 3];
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++) {
+    for (int mi = 0; mi < MI; mi++) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 ct[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-        for (int it = 0; it < 8; it++) {
-            const int row = it * 4 + (lane >> 4);
-            const int m = m0 + wr * 64 + mi * 32 + row;
-            float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane & 15) * 4);
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int row = it * RPI + (lane / LPR);
+            const int m = m0 + wr * (32 * MI) + mi * 32 + row;
+            float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane % LPR) * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (m >= p.M || cn >= p.N) continue;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
     if (do_colsum && m0 + tid < p.M) p.colsum[(int64_t)bz * p.M + m0 + tid] = csum;
 
     __syncthreads();   // the staging buffers are free now
-    store_output(p, acc, reinterpret_cast<float *>(&smem[0][0][0]), m0, n0, bz);
+    store_output<2, 2>(p, acc, reinterpret_cast<float *>(&smem[0][0][0]), m0, n0, bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,35 +364,52 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPlane16 = 4096;              // 128 x 16 bf16, RC or RS
-constexpr int kStage16 = 6 * kPlane16;      // A planes then B planes
+// Workgroup tiles.  TM x TN outputs per 256-thread workgroup, TM, TN in {128, 64}; the four waves sit 2 x 2
+// and own (TM/2) x (TN/2) each, i.e. MI x NI = (TM/64) x (TN/64) MFMA tiles of 32 x 32.  128 x 128 has the best
+// ratio of matrix work to split / LDS work and is used whenever it yields enough workgroups to fill the chip;
+// the smaller tiles exist for small batches (a local batch of 8192 over 8 GPUs, Criteo-Kaggle's 2048), where
+// 128 x 128 leaves most compute units without a workgroup.
+//
+// An operand tile of R (= TM or TN) output indices x 32 reduction elements is loaded as two half-steps of
+// R/64 16-byte pieces per thread each.
+constexpr int plane_bytes(int R) { return R * 32; }   // R x 16 bf16
 
 __device__ inline int rc_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch (0/1) of row `row`
     return 32 * row + 16 * (ch ^ ((row >> 3) & 1));
 }
 
-// Register image of one 128 x 32 operand tile: reg[2h], reg[2h+1] belong to half-step h.
-//   RC: reg[2h+v] = row (tid>>2) + 64v, reduction elements 16h + 4(tid&3) .. +3
-//   RS: reg[2h+v] = reduction row 16h + (tid>>5) + 8v, output elements 4(tid&31) .. +3
+// RS planes: [16][R] bf16.  The transposing read takes, per 32 lanes, four rows x 64 bytes; the swizzle puts
+// those four pieces on four different 64-byte bank ranges (R = 128: rows are 256 bytes, a multiple of the bank
+// window, so the row's low bits pick the range; R = 64: rows are 128 bytes, rows r and r+2 would collide).
+template <int R>
+__device__ inline int rs_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch of row `row`
+    if constexpr (R == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    else return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)));
+}
+
+// Register image of one R x 32 operand tile: reg[h*P + v] (P = R/64 pieces) belongs to half-step h.
+//   RC: piece v = row (tid>>2) + 64v, reduction elements 16h + 4(tid&3) .. +3
+//   RS: piece v = reduction row 16h + tid/(R/4) + (1024/R) v, output elements 4(tid % (R/4)) .. +3
 // Addresses are a wave-uniform tile origin (scalar registers) plus a per-thread byte offset that
 // does not change over the reduction loop.
-template <bool RC>
+template <bool RC, int R>
 struct TileAddr {
     const float *origin;   // element (o0, 0) of the operand
     int64_t ld;
     int o0, o_end;
-    unsigned off[2];       // byte offsets of this thread's two 16-byte pieces inside a half tile
+    unsigned off[R / 64];  // byte offsets of this thread's 16-byte pieces inside a half tile
 };
 
-template <bool RC>
-__device__ inline TileAddr<RC> make_tile_addr(const float *base, int64_t ld, int o0, int o_end) {
-    TileAddr<RC> t;
+template <bool RC, int R>
+__device__ inline TileAddr<RC, R> make_tile_addr(const float *base, int64_t ld, int o0, int o_end) {
+    TileAddr<RC, R> t;
     const int tid = threadIdx.x;
+    constexpr int LPR = R / 4;   // RS: lanes per reduction row
     t.ld = ld; t.o0 = o0; t.o_end = o_end;
     if constexpr (RC) {
         t.origin = base + (int64_t)o0 * ld;
 #pragma unroll
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < R / 64; v++) {
             const int o = o0 + (tid >> 2) + 64 * v;
             const int oc = o < o_end ? o : o_end - 1;   // surplus rows only feed outputs that are never stored
             t.off[v] = (unsigned)((oc - o0) * (int)ld + (tid & 3) * 4) * 4u;
@@ -397,35 +417,38 @@ __device__ inline TileAddr<RC> make_tile_addr(const float *base, int64_t ld, int
     } else {
         t.origin = base + o0;
 #pragma unroll
-        for (int v = 0; v < 2; v++) t.off[v] = (unsigned)(((tid >> 5) + 8 * v) * (int)ld + (tid & 31) * 4) * 4u;
+        for (int v = 0; v < R / 64; v++)
+            t.off[v] = (unsigned)((tid / LPR + (256 / LPR) * v) * (int)ld + (tid % LPR) * 4) * 4u;
     }
     return t;
 }
 
 // 16-byte loads of half h of the tile whose reduction range starts at r0 (needs 16-byte aligned rows
 // and a full 32-deep tile; an RS tile must not run past the row's leading dimension)
-template <bool RC>
-__device__ inline void load_half_vec(const TileAddr<RC> &t, int r0, int h, f32x4 &x0, f32x4 &x1) {
+template <bool RC, int R>
+__device__ inline void load_half_vec(const TileAddr<RC, R> &t, int r0, int h, f32x4 *x) {
     // buffer loads: the wave-uniform half-tile origin travels in a scalar resource descriptor and each
     // piece costs one 32-bit offset register (no range check is wanted: the record count is the maximum)
     const float *o = RC ? t.origin + r0 + 16 * h : t.origin + (int64_t)(r0 + 16 * h) * t.ld;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(o), 0, 0xffffffff, 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    x0 = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)t.off[0], 0, 0));
-    x1 = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)t.off[1], 0, 0));
+#pragma unroll
+    for (int v = 0; v < R / 64; v++)
+        x[v] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)t.off[v], 0, 0));
 }
 
 // any shape / alignment: 4-byte loads from clamped addresses, zero beyond the operand's extent
-template <bool RC>
-__device__ inline void load_half_scalar(const TileAddr<RC> &t, int r0, int r_end, int h, f32x4 &x0, f32x4 &x1) {
+template <bool RC, int R>
+__device__ inline void load_half_scalar(const TileAddr<RC, R> &t, int r0, int r_end, int h, f32x4 *xo) {
     const int tid = threadIdx.x;
+    constexpr int LPR = R / 4;
     const float *base = RC ? t.origin - (int64_t)t.o0 * t.ld : t.origin - t.o0;
 #pragma unroll
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < R / 64; v++) {
         int o, r;
         if constexpr (RC) { o = t.o0 + (tid >> 2) + 64 * v; r = r0 + 16 * h + (tid & 3) * 4; }
-        else { r = r0 + 16 * h + (tid >> 5) + 8 * v; o = t.o0 + (tid & 31) * 4; }
+        else { r = r0 + 16 * h + tid / LPR + (256 / LPR) * v; o = t.o0 + (tid % LPR) * 4; }
         f32x4 x;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -435,7 +458,7 @@ __device__ inline void load_half_scalar(const TileAddr<RC> &t, int r0, int r_end
             const float e = RC ? base[(int64_t)oc * t.ld + rc] : base[(int64_t)rc * t.ld + oc];
             x[q] = ok ? e : 0.f;
         }
-        if (v == 0) x0 = x; else x1 = x;
+        xo[v] = x;
     }
 }
 
@@ -453,32 +476,29 @@ __device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &
     l = __builtin_bit_cast(unsigned, lb);
 }
 
-__device__ inline int rs_chunk_off(int row, int ch) {   // byte offset of 16-byte chunk ch of row `row`
-    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-
-// split the two registers of one half-step and write the pieces to the three planes at `planes`
-template <bool RC>
-__device__ inline void split_store_half(unsigned char *__restrict__ planes, const f32x4 &v0, const f32x4 &v1) {
+// split the registers of one half-step and write the pieces to the three planes at `planes`
+template <bool RC, int R>
+__device__ inline void split_store_half(unsigned char *__restrict__ planes, const f32x4 *xs) {
     const int tid = threadIdx.x;
+    constexpr int LPR = R / 4;
 #pragma unroll
-    for (int v = 0; v < 2; v++) {
-        const f32x4 x = v ? v1 : v0;
+    for (int v = 0; v < R / 64; v++) {
+        const f32x4 x = xs[v];
         int off;
         if constexpr (RC) off = rc_chunk_off((tid >> 2) + 64 * v, (tid & 3) >> 1) + 8 * (tid & 1);
-        else off = rs_chunk_off((tid >> 5) + 8 * v, (tid & 31) >> 1) + 8 * (tid & 1);
+        else off = rs_chunk_off<R>(tid / LPR + (256 / LPR) * v, (tid % LPR) >> 1) + 8 * (tid & 1);
         unsigned h0, m0, l0, h1, m1, l1;
         split3_pair(f32x2{x[0], x[1]}, h0, m0, l0);
         split3_pair(f32x2{x[2], x[3]}, h1, m1, l1);
         *reinterpret_cast<u32x2 *>(planes + off) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2 *>(planes + kPlane16 + off) = u32x2{m0, m1};
-        *reinterpret_cast<u32x2 *>(planes + 2 * kPlane16 + off) = u32x2{l0, l1};
+        *reinterpret_cast<u32x2 *>(planes + plane_bytes(R) + off) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2 *>(planes + 2 * plane_bytes(R) + off) = u32x2{l0, l1};
     }
 }
 
 // 8 consecutive reduction elements (lane half h takes 8h..8h+7 of the 16-deep half-step) of output
 // index o_base + (lane & 31), from one plane
-template <bool RC>
+template <bool RC, int R>
 __device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, int o_base) {
     const int lane = threadIdx.x & 63;
     if constexpr (RC) {
@@ -492,9 +512,9 @@ __device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, in
         const int row0 = 8 * h + q;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4 *)(plane + rs_chunk_off(row0, ch) + 8 * (pp & 1)));
+            (lds_s16x4 *)(plane + rs_chunk_off<R>(row0, ch) + 8 * (pp & 1)));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4 *)(plane + rs_chunk_off(row0 + 4, ch) + 8 * (pp & 1)));
+            (lds_s16x4 *)(plane + rs_chunk_off<R>(row0 + 4, ch) + 8 * (pp & 1)));
         const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, t);
     }
@@ -504,31 +524,33 @@ __device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, in
 // it.  Keeps the bf16 split of a prefetched tile in the half-step it belongs to (it is plain
 // arithmetic on loaded registers, which the compiler would otherwise start right behind the loads,
 // waiting for them with whole MFMA blocks still to come).
-__device__ inline void pin_here(f32x4 &a, f32x4 &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ inline void pin_here(f32x4 &a) { asm volatile("" : "+v"(a)); }
 
-// the 12 fragments of one 16-deep half-step of the wave's 64x64 output, out of one stage
+// the fragments of one 16-deep half-step of the wave's output block, out of one stage
+template <int MI, int NI>
 struct Frags {
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[MI][3], b[NI][3];
 };
 
-template <bool A_RC, bool B_RC>
-__device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags &f) {
-    const unsigned char *pa = stage, *pb = stage + 3 * kPlane16;
+template <bool A_RC, bool B_RC, int TM, int TN>
+__device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags<TM / 64, TN / 64> &f) {
+    const unsigned char *pa = stage, *pb = stage + 3 * plane_bytes(TM);
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            f.a[i][pl] = load_frag16<A_RC>(pa + pl * kPlane16, wr * 64 + i * 32);
-            f.b[i][pl] = load_frag16<B_RC>(pb + pl * kPlane16, wc * 64 + i * 32);
-        }
+        for (int i = 0; i < TM / 64; i++) f.a[i][pl] = load_frag16<A_RC, TM>(pa + pl * plane_bytes(TM), wr * (TM / 2) + i * 32);
+#pragma unroll
+        for (int i = 0; i < TN / 64; i++) f.b[i][pl] = load_frag16<B_RC, TN>(pb + pl * plane_bytes(TN), wc * (TN / 2) + i * 32);
+    }
 }
 
-// 24 MFMAs: six cross terms for each of the four 32x32 accumulators, smallest terms first
-__device__ inline void mfma_frags(const Frags &f, f32x16 (&acc)[2][2]) {
+// six cross terms for each of the wave's 32x32 accumulators, smallest terms first
+template <int MI, int NI>
+__device__ inline void mfma_frags(const Frags<MI, NI> &f, f32x16 (&acc)[MI][NI]) {
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
+        for (int ni = 0; ni < NI; ni++) {
             f32x16 c = acc[mi][ni];
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][2], f.b[ni][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][1], f.b[ni][1], c, 0, 0, 0);
@@ -540,30 +562,34 @@ __device__ inline void mfma_frags(const Frags &f, f32x16 (&acc)[2][2]) {
         }
 }
 
-template <bool A_RC, bool B_RC>
-__device__ inline void mfma_half(const unsigned char *__restrict__ stage, int wr, int wc, f32x16 (&acc)[2][2]) {
-    Frags f;
-    load_frags<A_RC, B_RC>(stage, wr, wc, f);
-    mfma_frags(f, acc);
-}
-
-// Scheduling recipe for one half-step region (12 fragment reads, 24 MFMAs, the split of 16 elements
-// per lane and its 6 LDS writes): all reads first, then three split operations behind every MFMA,
-// the writes of an operand once its pieces are complete.
-__device__ inline void interleave_half() {
-    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
-#pragma unroll
-    for (int i = 0; i < 24; i++) {
+// Scheduling recipe for one half-step region (3 (MI+NI) fragment reads, 6 MI NI MFMAs, the split of
+// 4 (MI+NI) elements per lane -- 18 vector operations per piece -- and its LDS writes): all reads first, then
+// the split operations spread evenly behind the MFMAs, the writes of an operand once its pieces are complete.
+// (128 x 128: three split operations behind every MFMA.)
+template <int I, int MI, int NI>
+__device__ inline void interleave_from() {
+    constexpr int kMfma = 6 * MI * NI, kValu = 18 * (MI + NI), kWrites = (3 * (MI + NI)) / 4;
+    if constexpr (I < kMfma) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        if (i == 11 || i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (kValu * (I + 1)) / kMfma - (kValu * I) / kMfma, 0);
+        if constexpr (I == kMfma / 2 - 1 || I == kMfma - 1) __builtin_amdgcn_sched_group_barrier(0x200, kWrites, 0);
+        interleave_from<I + 1, MI, NI>();
     }
 }
 
-template <bool A_RC, bool B_RC>
+template <int MI, int NI>
+__device__ inline void interleave_half() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + NI), 0);
+    interleave_from<0, MI, NI>();
+}
+
+template <bool A_RC, bool B_RC, int TM, int TN>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage16];
-    unsigned char *const s0 = smem, *const s1 = smem + kStage16;
+    constexpr int MI = TM / 64, NI = TN / 64, PA = TM / 64, PB = TN / 64;
+    constexpr int kStage = 3 * plane_bytes(TM) + 3 * plane_bytes(TN);   // A planes then B planes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage];
+    static_assert(2 * kStage >= 4 * 32 * (32 * NI + 4) * 4, "the output staging must fit the operand stages");
+    unsigned char *const s0 = smem, *const s1 = smem + kStage;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -572,22 +598,22 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
     const int bx = tile % p.gx, by = (tile / p.gx) % p.gy, bz = tile / (p.gx * p.gy);
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = by * TM, n0 = bx * TN;
     const int k_begin = bz * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int steps = (k_end - k_begin + BK - 1) / BK;
     const int full_steps = (k_end - k_begin) / BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
-    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + BM <= p.M || m0 + BM <= p.lda) &&
-                          (B_RC || n0 + BN <= p.N || n0 + BN <= p.ldb);
+    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + TM <= p.M || m0 + TM <= p.lda) &&
+                          (B_RC || n0 + TN <= p.N || n0 + TN <= p.ldb);
 
     // bias gradient (weight-gradient product only): this thread's four output rows of the A tile,
     // summed over every staged reduction row
@@ -595,65 +621,85 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     // split half-step h of a raw tile pair into `stage` (`live` false: the registers hold no new
     // tile and the stage is never read; only the bias-gradient sum must skip them)
-    auto stage_half = [&](unsigned char *stage, f32x4 (&xa)[4], f32x4 (&xb)[4], int h, bool live) {
+    auto stage_half = [&](unsigned char *stage, f32x4 (&xa)[2 * PA], f32x4 (&xb)[2 * PB], int h, bool live) {
         if constexpr (!A_RC) {
             if (do_colsum) {
-                const f32x4 add = xa[2 * h] + xa[2 * h + 1];
+                f32x4 add = xa[h * PA];
+#pragma unroll
+                for (int v = 1; v < PA; v++) add += xa[h * PA + v];
                 cs += live ? add : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        split_store_half<A_RC>(stage, xa[2 * h], xa[2 * h + 1]);
-        split_store_half<B_RC>(stage + 3 * kPlane16, xb[2 * h], xb[2 * h + 1]);
+        split_store_half<A_RC, TM>(stage, &xa[h * PA]);
+        split_store_half<B_RC, TN>(stage + 3 * plane_bytes(TM), &xb[h * PB]);
     };
 
     // Tiles [t_begin, t_end) of the reduction through the two-stage pipeline.  VEC: 16-byte loads
     // (full 32-deep tiles of aligned operands), else clamped 4-byte loads with zero fill.
-    const TileAddr<A_RC> ta = make_tile_addr<A_RC>(p.A, p.lda, m0, p.M);
-    const TileAddr<B_RC> tb = make_tile_addr<B_RC>(p.B, p.ldb, n0, p.N);
-    f32x4 xa[4], xb[4], ya[4], yb[4];
-    auto run = [&](auto vec_tag, int t_begin, int t_end) {
+    const TileAddr<A_RC, TM> ta = make_tile_addr<A_RC, TM>(p.A, p.lda, m0, p.M);
+    const TileAddr<B_RC, TN> tb = make_tile_addr<B_RC, TN>(p.B, p.ldb, n0, p.N);
+    f32x4 xa[2 * PA], xb[2 * PB], ya[2 * PA], yb[2 * PB];
+    // zero the elements of half h of a raw RC tile whose reduction index is k_end or beyond (tile at r0)
+    auto mask_tail = [&](f32x4 *x, int pieces, int r0, int h) {
+        const int r = r0 + 16 * h + (tid & 3) * 4;
+        for (int v = 0; v < pieces; v++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[v][q] = r + q < k_end ? x[v][q] : 0.f;
+    };
+    auto run = [&](auto vec_tag, auto mask_tag, int t_begin, int t_end) {
         constexpr bool VEC = decltype(vec_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value;   // 16-byte loads of a partial last tile, surplus elements zeroed
         // request half h of tile tt (clamped: surplus requests re-read the last tile)
-        auto load = [&](int tt, int h, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
+        auto load = [&](int tt, int h, f32x4 (&ra)[2 * PA], f32x4 (&rb)[2 * PB]) {
             const int tc = tt < t_end ? tt : t_end - 1;
             const int r0 = k_begin + tc * BK;
             if constexpr (VEC) {
-                load_half_vec<A_RC>(ta, r0, h, ra[2 * h], ra[2 * h + 1]);
-                load_half_vec<B_RC>(tb, r0, h, rb[2 * h], rb[2 * h + 1]);
+                load_half_vec<A_RC, TM>(ta, r0, h, &ra[h * PA]);
+                load_half_vec<B_RC, TN>(tb, r0, h, &rb[h * PB]);
             } else {
-                load_half_scalar<A_RC>(ta, r0, k_end, h, ra[2 * h], ra[2 * h + 1]);
-                load_half_scalar<B_RC>(tb, r0, k_end, h, rb[2 * h], rb[2 * h + 1]);
+                load_half_scalar<A_RC, TM>(ta, r0, k_end, h, &ra[h * PA]);
+                load_half_scalar<B_RC, TN>(tb, r0, k_end, h, &rb[h * PB]);
             }
+        };
+        auto pin = [&](f32x4 (&ra)[2 * PA], f32x4 (&rb)[2 * PB], int h) {
+#pragma unroll
+            for (int v = 0; v < PA; v++) pin_here(ra[h * PA + v]);
+#pragma unroll
+            for (int v = 0; v < PB; v++) pin_here(rb[h * PB + v]);
         };
         // One tile = two half-steps.  On entry stage 0 holds half 0 of tile tt, (ua, ub) hold the raw
         // tile tt and (va, vb) half 0 of tile tt+1 (in flight or landed).  Every half-step requests the
         // half tile that is staged two half-steps later, into the registers staged one half-step ago.
-        auto tile_step = [&](int tt, f32x4 (&ua)[4], f32x4 (&ub)[4], f32x4 (&va)[4], f32x4 (&vb)[4]) {
-            Frags f;
+        auto tile_step = [&](int tt, f32x4 (&ua)[2 * PA], f32x4 (&ub)[2 * PB], f32x4 (&va)[2 * PA], f32x4 (&vb)[2 * PB]) {
+            Frags<MI, NI> f;
             load(tt + 1, 1, va, vb);
             __builtin_amdgcn_sched_barrier(0);   // the requests go out ahead of the MFMA block
-            load_frags<A_RC, B_RC>(s0, wr, wc, f);   // reads first: the writes below go to the other stage
-            pin_here(ua[2], ua[3]);
-            pin_here(ub[2], ub[3]);
+            load_frags<A_RC, B_RC, TM, TN>(s0, wr, wc, f);   // reads first: the writes below go to the other stage
+            pin(ua, ub, 1);
+            if constexpr (MASK) { mask_tail(&ua[PA], PA, k_begin + tt * BK, 1); mask_tail(&ub[PB], PB, k_begin + tt * BK, 1); }
             stage_half(s1, ua, ub, 1, true);
-            mfma_frags(f, acc);
-            interleave_half();
+            mfma_frags<MI, NI>(f, acc);
+            interleave_half<MI, NI>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             load(tt + 2, 0, ua, ub);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags<A_RC, B_RC>(s1, wr, wc, f);
-            pin_here(va[0], va[1]);
-            pin_here(vb[0], vb[1]);
+            load_frags<A_RC, B_RC, TM, TN>(s1, wr, wc, f);
+            pin(va, vb, 0);
+            if constexpr (MASK) {
+                const int tn = tt + 1 < t_end ? tt + 1 : t_end - 1;
+                mask_tail(&va[0], PA, k_begin + tn * BK, 0); mask_tail(&vb[0], PB, k_begin + tn * BK, 0);
+            }
             stage_half(s0, va, vb, 0, tt + 1 < t_end);
-            mfma_frags(f, acc);
-            interleave_half();
+            mfma_frags<MI, NI>(f, acc);
+            interleave_half<MI, NI>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         };
         load(t_begin, 0, xa, xb);
         load(t_begin, 1, xa, xb);
         load(t_begin + 1, 0, ya, yb);
+        if constexpr (MASK) { mask_tail(&xa[0], PA, k_begin + t_begin * BK, 0); mask_tail(&xb[0], PB, k_begin + t_begin * BK, 0); }
         stage_half(s0, xa, xb, 0, true);
         __syncthreads();
         for (int t = t_begin; t < t_end; t += 2) {
@@ -664,39 +710,62 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     };
     int t_done = 0;
     if (vec_tile && full_steps > 0) {
-        run(std::true_type{}, 0, full_steps);
+        run(std::true_type{}, std::false_type{}, 0, full_steps);
         t_done = full_steps;
     }
-    if (t_done < steps) run(std::false_type{}, t_done, steps);   // edge tiles, unaligned operands, partial last tile
+    if constexpr (A_RC && B_RC) {
+        // partial last tile of reduction-contiguous operands whose rows are long enough to be read past k_end
+        // (padded leading dimensions): 16-byte loads, the surplus elements zeroed in registers
+        const int64_t r_hi = (int64_t)k_begin + (int64_t)steps * BK;
+        if (t_done < steps && vec_tile && r_hi <= p.lda && r_hi <= p.ldb) {
+            run(std::true_type{}, std::true_type{}, t_done, steps);
+            t_done = steps;
+        }
+    }
+    if (t_done < steps) run(std::false_type{}, std::false_type{}, t_done, steps);   // edge tiles, unaligned operands
 
     float *fsm = reinterpret_cast<float *>(smem);
     if constexpr (!A_RC) {
         if (do_colsum) {
-            // thread (tid>>5, tid&31) holds the sums of output rows 4*(tid&31).. over its reduction rows
-            *reinterpret_cast<f32x4 *>(fsm + (tid >> 5) * BM + (tid & 31) * 4) = cs;
+            // thread (tid / (TM/4), tid % (TM/4)) holds the sums of output rows 4 (tid % (TM/4)).. over its reduction rows
+            constexpr int LPR = TM / 4, GROUPS = 256 / LPR;
+            *reinterpret_cast<f32x4 *>(fsm + (tid / LPR) * TM + (tid % LPR) * 4) = cs;
             __syncthreads();
-            if (tid < BM && m0 + tid < p.M) {
+            if (tid < TM && m0 + tid < p.M) {
                 float a = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; w++) a += fsm[w * BM + tid];
+                for (int w = 0; w < GROUPS; w++) a += fsm[w * TM + tid];
                 p.colsum[(int64_t)bz * p.M + m0 + tid] = a;
             }
             __syncthreads();
         }
     }
-    store_output(p, acc, fsm, m0, n0, bz);
+    store_output<MI, NI>(p, acc, fsm, m0, n0, bz);
 }
 
 // out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out).  A 256-thread workgroup owns
 // 64 consecutive outputs; thread (q, e) adds the slabs s = q, q+4, ... of output e with eight loads in
-// flight, and the four partial sums meet in LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, int64_t stride,
-                                                           int rows, int cols, float *__restrict__ out,
-                                                           int64_t ld_out) {
+// flight, and the four partial sums meet in LDS in a fixed order (deterministic).  One launch serves two
+// such problems with the same number of slabs (a weight gradient and its bias gradient): workgroups
+// [0, blocks_a) take the first, the rest the second.
+struct SlabSum {
+    const float *slabs;
+    int64_t stride;
+    int rows, cols;
+    float *out;
+    int64_t ld_out;
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(SlabSum pa, SlabSum pb, int splits, unsigned blocks_a) {
     __shared__ float part[4][64];
-    const int64_t n = (int64_t)rows * cols;
+    const bool second = blockIdx.x >= blocks_a;
+    const SlabSum p = second ? pb : pa;
+    const unsigned bid = second ? blockIdx.x - blocks_a : blockIdx.x;
+    const unsigned nblk = second ? gridDim.x - blocks_a : blocks_a;
+    const float *__restrict__ slabs = p.slabs;
+    const int64_t n = (int64_t)p.rows * p.cols;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n; i0 += (int64_t)gridDim.x * 64) {
+    for (int64_t i0 = (int64_t)bid * 64; i0 < n; i0 += (int64_t)nblk * 64) {
         const int64_t i = i0 + e;
         float a = 0.f;
         if (i < n) {
@@ -704,21 +773,34 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restri
             for (; s + 28 < splits; s += 32) {
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
+                for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(s + 4 * u) * p.stride + i];
 #pragma unroll
                 for (int u = 0; u < 8; u++) a += v[u];
             }
-            for (; s < splits; s += 4) a += slabs[(int64_t)s * stride + i];
+            for (; s < splits; s += 4) a += slabs[(int64_t)s * p.stride + i];
         }
         part[q][e] = a;
         __syncthreads();
         if (q == 0 && i < n) {
             const float t = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-            const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-            out[(int64_t)r * ld_out + c] = t;
+            const int r = (int)(i / p.cols), c = (int)(i - (int64_t)r * p.cols);
+            p.out[(int64_t)r * p.ld_out + c] = t;
         }
         __syncthreads();
     }
+}
+
+// dW (and db, if wanted) from their partial sums, one launch
+static int launch_reduce(const float *slabs, int64_t stride, int N, int K, float *dw, int64_t dw_ld, const float *db_slabs,
+                         float *db, int splits, hipStream_t s) {
+    const int64_t n = (int64_t)N * K;
+    const unsigned blocks_a = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
+    const unsigned blocks_b = db ? (unsigned)ceil_div(N, 64) : 0u;
+    SlabSum a{slabs, stride, N, K, dw, dw_ld};
+    SlabSum b{db_slabs, (int64_t)N, 1, N, db, (int64_t)N};
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, s, a, b, splits, blocks_a);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
 }
 
 __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__ g, int64_t n, float lr) {
@@ -726,17 +808,60 @@ __global__ void sgd_step_kernel(float *__restrict__ w, const float *__restrict__
         w[i] -= lr * g[i];
 }
 
+// Tile shapes by falling efficiency.  A launch takes the first one that gives every compute unit a
+// workgroup (measured at batch 8192: 256 workgroups of 128 x 128 beat 512 of 128 x 64; below 256 the
+// smaller tiles win), else the one with the most workgroups (ties: the larger tile).  A split reduction
+// aims at two workgroups per compute unit.
+struct TileShape { int tm, tn; };
+static const TileShape kTiles[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+constexpr int64_t kWantWgs = 512, kTileWgs = 256;
+
+static int splits_for(int M_red, int64_t tiles) {
+    // enough workgroups for 256 CUs x 2, each split at least 8 reduction steps deep
+    int64_t want = ceil_div(kWantWgs, tiles);
+    int64_t max_by_depth = M_red / (BK * 8);
+    if (max_by_depth < 1) max_by_depth = 1;
+    int64_t s = want < max_by_depth ? want : max_by_depth;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+// tile for an [M,N] output; red > 0: the reduction (of that length) may be split over workgroups as well
+static TileShape pick_tile(int64_t M, int64_t N, int64_t red, int *splits_out) {
+    static const int forced = [] { const char *e = getenv("DLRM_GEMM_TILE"); return e ? atoi(e) : -1; }();   // tuning aid
+    int best = 0, best_splits = 1;
+    int64_t best_wgs = -1;
+    for (int i = 0; i < 4; i++) {
+        const int64_t tiles = ceil_div(M, kTiles[i].tm) * ceil_div(N, kTiles[i].tn);
+        const int sp = red > 0 ? splits_for((int)red, tiles) : 1;
+        const int64_t wgs = tiles * sp;
+        if (forced == i || (forced < 0 && wgs >= kTileWgs)) { best = i; best_splits = sp; break; }
+        if (forced < 0 && wgs > best_wgs) { best = i; best_splits = sp; best_wgs = wgs; }
+    }
+    if (splits_out) *splits_out = best_splits;
+    return kTiles[best];
+}
+
+template <bool A_RC, bool B_RC, int TM, int TN>
+static void launch_bf16x3(const GemmParams &p, unsigned nwg, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<A_RC, B_RC, TM, TN>), dim3(nwg), dim3(kGemmThreads), 0, s, p);
+}
+
 template <bool A_RC, bool B_RC>
-static int launch_gemm(GemmParams p, int splits, int mode, hipStream_t s) {
+static int launch_gemm(GemmParams p, int splits, TileShape ts, int mode, hipStream_t s) {
     DLRM_REQUIRE(mode == DLRM_GEMM_DEFAULT || mode == DLRM_GEMM_F32_MFMA || mode == DLRM_GEMM_BF16X3,
                  "gemm_mode must be DLRM_GEMM_DEFAULT, _F32_MFMA or _BF16X3, got %d", mode);
-    p.gx = (int)ceil_div(p.N, BN); p.gy = (int)ceil_div(p.M, BM); p.gz = splits;
+    if (mode == DLRM_GEMM_F32_MFMA) ts = TileShape{BM, BN};    // the float32-MFMA kernel has the one tile
+    p.gx = (int)ceil_div(p.N, ts.tn); p.gy = (int)ceil_div(p.M, ts.tm); p.gz = splits;
     const int64_t nwg = (int64_t)p.gx * p.gy * p.gz;
     DLRM_REQUIRE(nwg < (1ll << 31), "GEMM grid too large");
-    if (mode != DLRM_GEMM_F32_MFMA)
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
-    else
+    if (mode == DLRM_GEMM_F32_MFMA)
         hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
+    else if (ts.tm == 128 && ts.tn == 128) launch_bf16x3<A_RC, B_RC, 128, 128>(p, (unsigned)nwg, s);
+    else if (ts.tm == 128) launch_bf16x3<A_RC, B_RC, 128, 64>(p, (unsigned)nwg, s);
+    else if (ts.tn == 128) launch_bf16x3<A_RC, B_RC, 64, 128>(p, (unsigned)nwg, s);
+    else launch_bf16x3<A_RC, B_RC, 64, 64>(p, (unsigned)nwg, s);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -745,15 +870,13 @@ static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 1
 // rows of an operand start on 16-byte boundaries (otherwise the kernel falls back to 4-byte loads)
 static int vec_ok(const void *p, int64_t ld) { return aligned16(p) && ld % 4 == 0; }
 
-static int choose_splits(int M_red, int tiles) {
-    // enough workgroups for 256 CUs x 2, each split at least 8 reduction steps deep
-    int want = (int)ceil_div(512, tiles);
-    int max_by_depth = M_red / (BK * 8);
-    if (max_by_depth < 1) max_by_depth = 1;
-    int s = want < max_by_depth ? want : max_by_depth;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
-    return s;
+// weight gradient [N,K] over a batch of M: tile and reduction split per evaluation mode
+static TileShape wgrad_shape(int64_t M, int N, int K, int mode, int *splits) {
+    if (mode == DLRM_GEMM_F32_MFMA) {
+        *splits = splits_for((int)M, ceil_div(N, BM) * ceil_div(K, BN));
+        return TileShape{BM, BN};
+    }
+    return pick_tile(N, K, M, splits);
 }
 
 }  // namespace dlrm
@@ -779,7 +902,7 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->K, BK) * BK;
-    return launch_gemm<true, true>(p, 1, l->gemm_mode, as_stream(stream));
+    return launch_gemm<true, true>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
 extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream) {
@@ -799,13 +922,16 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     p.mask = l->d_relu_mask; p.mask_ld = l->relu_mask_ld;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->N, BK) * BK;
-    return launch_gemm<true, false>(p, 1, l->gemm_mode, as_stream(stream));
+    return launch_gemm<true, false>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
 extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes) {
     DLRM_REQUIRE(bytes != nullptr && M >= 0 && N >= 1 && K >= 1, "bad arguments");
-    const int tiles = (int)(ceil_div(N, BM) * ceil_div(K, BN));
-    const int splits = choose_splits((int)M, tiles);
+    // the split depends on the tile, which depends on the evaluation mode: room for either
+    int s1 = 1, s2 = 1;
+    wgrad_shape(M, N, K, DLRM_GEMM_BF16X3, &s1);
+    wgrad_shape(M, N, K, DLRM_GEMM_F32_MFMA, &s2);
+    const int splits = s1 > s2 ? s1 : s2;
     *bytes = sizeof(float) * ((size_t)splits * N * K + (size_t)splits * N) + 256;
     return DLRM_OK;
 }
@@ -823,8 +949,8 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
                  need);
     DLRM_REQUIRE(aligned16(d_workspace), "workspace must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    const int tiles = (int)(ceil_div(l->N, BM) * ceil_div(l->K, BN));
-    const int splits = choose_splits((int)l->M, tiles);
+    int splits = 1;
+    const TileShape ts = wgrad_shape(l->M, l->N, l->K, l->gemm_mode, &splits);
     float *slabs = static_cast<float *>(d_workspace);
     const bool few_inputs = skinny_k_forward_ok(l->N, l->K);
     if (few_inputs || (l->N == 1 && gemv_backward_weight_ok(l->d_x, l->x_ld, l->K))) {
@@ -836,14 +962,7 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
                                   : gemv_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->K, splits,
                                                          &chunks, s);
         if (rc) return rc;
-        const int64_t n = (int64_t)l->N * l->K;
-        const unsigned blocks = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, chunks, n, l->N, l->K, l->d_dw, l->dw_ld);
-        if (l->d_db)
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 64)), dim3(256), 0, s, dbp, chunks,
-                               (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
-        DLRM_LAUNCH_CHECK();
-        return DLRM_OK;
+        return launch_reduce(slabs, (int64_t)l->N * l->K, l->N, l->K, l->d_dw, l->dw_ld, dbp, l->d_db, chunks, s);
     }
     GemmParams p{};
     p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_x; p.ldb = l->x_ld;
@@ -854,22 +973,14 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
     if (splits == 1) {
         p.C = l->d_dw; p.ldc = l->dw_ld;
         p.colsum = l->d_db;
-        if (int rc = launch_gemm<false, false>(p, 1, l->gemm_mode, s)) return rc;
+        if (int rc = launch_gemm<false, false>(p, 1, ts, l->gemm_mode, s)) return rc;
     } else {
         p.C = slabs; p.ldc = l->K; p.slab_stride = (int64_t)l->N * l->K;
         p.colsum = l->d_db ? db_partial : nullptr;
         const int real_splits = (int)ceil_div(l->M, p.k_per_split);
-        if (int rc = launch_gemm<false, false>(p, real_splits, l->gemm_mode, s)) return rc;
-        const int64_t n = (int64_t)l->N * l->K;
-        const unsigned blocks = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, s, slabs, real_splits, p.slab_stride,
-                           l->N, l->K, l->d_dw, l->dw_ld);
-        DLRM_LAUNCH_CHECK();
-        if (l->d_db) {
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(l->N, 64)), dim3(256), 0, s, db_partial,
-                               real_splits, (int64_t)l->N, 1, l->N, l->d_db, (int64_t)l->N);
-            DLRM_LAUNCH_CHECK();
-        }
+        if (int rc = launch_gemm<false, false>(p, real_splits, ts, l->gemm_mode, s)) return rc;
+        if (int rc = launch_reduce(slabs, p.slab_stride, l->N, l->K, l->d_dw, l->dw_ld, db_partial, l->d_db, real_splits, s))
+            return rc;
     }
     return DLRM_OK;
 }

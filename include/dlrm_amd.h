@@ -184,8 +184,10 @@ enum { DLRM_GEMM_DEFAULT = 0, DLRM_GEMM_F32_MFMA = 1, DLRM_GEMM_BF16X3 = 2 };
  * (src/dlrmtest.cpp:254-272; layers made by create_fc, :119-140).  W is [N,K]
  * row-major (torch layout).  Any shape and leading dimension is accepted (K = 13, 479, ...);
  * operands whose rows start on 16-byte boundaries (pointer 16-byte aligned, leading dimension
- * a multiple of 4 floats) are read with 16-byte loads, others with 4-byte loads.  Layers with at most
- * 16 inputs or a single output are no matrix product and run in one-pass float32 fma kernels.
+ * a multiple of 4 floats) are read with 16-byte loads, others with 4-byte loads.  A leading dimension is a
+ * promise that every row, the last one included, is readable up to it: when x_ld and w_ld both reach K rounded
+ * up to 32, the columns between K and that bound are loaded too (and discarded; they need not be zero).
+ * Layers with at most 16 inputs or a single output are no matrix product and run in one-pass float32 fma kernels.
  */
 typedef struct dlrm_linear {
     int64_t M;          /* rows of x (batch) */
