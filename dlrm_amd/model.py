@@ -452,6 +452,51 @@ class DLRM:
         else:
             dist.reduce_scatter_tensor(out, inp, group=self.pg)
 
+    def exchange_ids(self, local_indices, hotness=None):
+        """The index exchange of a sharded run.  local_indices: ids of THIS rank's batch slice for all tables,
+        table-major in the plan's feature order (bag (t', b) holds hotness[feature_order[t']] ids; default
+        cfg.lookups each) -- what CriteoBinReader(table_order=plan.feature_order, rank=..., world=...) returns.
+        Every rank needs the ids of ITS tables for the GLOBAL batch: the blocks of whole tables travel with one
+        all-to-all (block p of local_indices is exactly what rank p owns), those of row-wise split tables with an
+        all-gather; a regroup kernel lays them out table-major over the global batch.  Returns (indices, offsets)
+        as train_step / forward take them.  The reference is one process and slices one tensor
+        (src/dlrmtest.cpp:53-63, :150)."""
+        cfg, B, W = self.cfg, self.B, self.world
+        T = cfg.num_tables
+        hot = [cfg.lookups] * T if hotness is None else [int(h) for h in hotness]
+        order = self.plan.feature_order
+        dev, dt = local_indices.device, local_indices.dtype
+        per_rank = [sum(hot[t] for t in self.plan.tables_of_rank[p]) for p in range(self.plan.world)] \
+            if self.sharded else [sum(hot[t] for t in order)]
+        n_tw = sum(per_rank)
+        s_rw = sum(hot[t] for t in self.rw_tables)
+        assert local_indices.numel() == B * (n_tw + s_rw), "local_indices does not match batch x hotness"
+        mine = per_rank[self.rank] if self.sharded else n_tw
+
+        def hot_off(tables):
+            ho = [0]
+            for t in tables:
+                ho.append(ho[-1] + hot[t])
+            return torch.tensor(ho, dtype=torch.int32, device=dev)
+        Bg = self.Bg
+        indices = torch.empty(max(Bg * (mine + s_rw), 1), dtype=dt, device=dev)
+        offsets = torch.empty((self.Tl + self.Trw) * Bg + 1, dtype=dt, device=dev)
+        if not self.sharded:
+            ops.ids_regroup(local_indices, 1, B, self.Tl, hot_off(self.my_tables), 0, indices, offsets)
+            return indices[:Bg * mine], offsets
+        recv = torch.empty(max(W * B * mine, 1), dtype=dt, device=dev)
+        self._all_to_all(recv[:W * B * mine], local_indices[:B * n_tw], [B * mine] * W, [B * p for p in per_rank])
+        if self.Tl:
+            ops.ids_regroup(recv, W, B, self.Tl, hot_off(self.my_tables), 0, indices, offsets)
+        if self.Trw:
+            recv_rw = torch.empty(W * B * s_rw, dtype=dt, device=dev)
+            self._all_gather(recv_rw, local_indices[B * n_tw:].contiguous())
+            ops.ids_regroup(recv_rw, W, B, self.Trw, hot_off(self.rw_tables), Bg * mine, indices[Bg * mine:],
+                            offsets[self.Tl * Bg:])
+        elif not self.Tl:
+            offsets.zero_()
+        return indices[:Bg * (mine + s_rw)], offsets
+
     # The step is written once, as a schedule: a list of (kind, stream, fn) items.
     #   ("ops",  stream, fn)   fn() calls dlrm_amd.ops operators only (launched now, or recorded
     #                          into a dlrm_plan and replayed as one C call)

@@ -365,6 +365,21 @@ def copy_2d_(dst, src):
     return dst
 
 
+def ids_regroup(recv, world, local_batch, n_tables, hot_offsets=None, offset_base=0, indices=None, offsets=None):
+    """After the index exchange: recv = [rank][table][sample][hot] ids -> (indices table-major over the global
+    batch, CSR offsets raised by offset_base).  hot_offsets: device int32[n_tables + 1] or None (one id per bag)."""
+    _require_cuda(recv, hot_offsets, indices, offsets)
+    Bg = world * local_batch
+    if indices is None:
+        indices = torch.empty(recv.numel(), dtype=recv.dtype, device=recv.device)
+    if offsets is None:
+        offsets = torch.empty(n_tables * Bg + 1, dtype=recv.dtype, device=recv.device)
+    check(_capi.lib().dlrm_ids_regroup(_ptr(recv), C.c_int32(world), C.c_int64(local_batch), C.c_int32(n_tables),
+                                       _ptr(hot_offsets), C.c_int64(offset_base), _ptr(indices), _ptr(offsets),
+                                       _idx_dtype(recv), _stream()))
+    return indices, offsets
+
+
 def set_gemm_mode(mode):
     """How the linear operators issued from now on evaluate their float32 products (a field of every layer
     descriptor, so a recorded step keeps the mode it was recorded with): 0 float32 MFMA

@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1008
+#define DLRM_ABI_VERSION 1009
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -357,16 +357,33 @@ typedef struct dlrm_cache_state_t {
 
 /* ---- input decoding ------------------------------------------------------------------------
  *
- * Criteo click logs in the MLPerf-DLRM binary layout (per sample: int32 label, n_dense int32 counters,
- * n_sparse int32 hashed category ids), decoded on the device into the step's inputs: dense features
- * log(max(x,0)+1) [n, dense_ld] float32, labels float32, ids table-major (bag g = t*n + b, one id per
- * bag, taken modulo d_table_rows[t] when given) and offsets 0..n_sparse*n (n_sparse*n + 1 entries).
- * Replaces the float-encoded feature tensor of MyDataset (src/dlrmtest.cpp:299-334), which carries ids
- * as floats and is split again by create_emb (:53-63).
+ * Criteo click logs in the MLPerf-DLRM binary layout (per sample: int32 label, n_dense int32 counters, then the
+ * tables' hashed category ids as int32: one per table in the Criteo Terabyte files; hot[t] per table in the
+ * fixed-hotness multi-hot variant, d_hot_offsets = device int32[n_sparse+1] prefix sums of hot[], ids_per_sample
+ * their total), decoded on the device into the step's inputs: dense features log(max(x,0)+1) [n, dense_ld]
+ * float32, labels float32, ids table-major (bag g = t'*n + b holds hot ids, taken modulo d_table_rows[t] when
+ * given) and CSR offsets (n_sparse*n + 1 entries).  Output table t' is record table d_table_order[t'] (device
+ * int32[n_sparse]; NULL = record order; d_table_rows and d_hot_offsets are indexed by RECORD table): with a
+ * sharding plan's order the decoded ids of a local batch are, block by block, what the index exchange sends to
+ * each rank.  Replaces the float-encoded feature tensor of MyDataset (src/dlrmtest.cpp:299-334), which carries
+ * ids as floats and is split again by create_emb (:53-63).
  */
 int dlrm_criteo_decode(const int32_t *d_records, int64_t n_samples, int32_t n_dense, int32_t n_sparse,
-                       const int64_t *d_table_rows, float *d_dense, int64_t dense_ld, float *d_labels,
+                       const int64_t *d_table_rows, const int32_t *d_table_order, const int32_t *d_hot_offsets,
+                       int32_t ids_per_sample, float *d_dense, int64_t dense_ld, float *d_labels,
                        void *d_indices, void *d_offsets, int32_t idx_dtype, dlrm_stream_t stream);
+/*
+ * After the index exchange of a sharded run (the reference is one process; its closest relative is create_emb
+ * taking one table's columns out of the batch, src/dlrmtest.cpp:53-63): d_recv holds, from every rank r in
+ * order, the ids of this rank's n_tables tables for r's local_batch samples ([r][table][sample][hot]);
+ * d_indices receives them table-major over the global batch (sample r*local_batch + b), d_offsets the CSR
+ * offsets (n_tables*world*local_batch + 1), each raised by offset_base (d_indices may be the tail of a longer
+ * index array whose head holds other tables).  d_hot_offsets: device int32[n_tables+1] prefix sums of these
+ * tables' hotness, NULL = one id per bag.
+ */
+int dlrm_ids_regroup(const void *d_recv, int32_t world, int64_t local_batch, int32_t n_tables,
+                     const int32_t *d_hot_offsets, int64_t offset_base, void *d_indices, void *d_offsets,
+                     int32_t idx_dtype, dlrm_stream_t stream);
 
 /* ---- recorded step ------------------------------------------------------------------------
  *
@@ -593,7 +610,9 @@ int dlrm_comm_destroy(dlrm_comm *c);
 /* d_buf[i] = sum over ranks, in place (the flat MLP gradient buffer). */
 int dlrm_comm_all_reduce_sum(dlrm_comm *c, float *d_buf, int64_t n, dlrm_stream_t stream);
 /* Floats for peer p are h_send_counts[p] consecutive elements of d_send (peers in rank order); what peer p
- * sends arrives as h_recv_counts[p] consecutive elements of d_recv. */
+ * sends arrives as h_recv_counts[p] consecutive elements of d_recv.  The exchange moves 4-byte words without
+ * looking at them (as does dlrm_comm_all_gather): the index exchange passes its int32 ids through the same calls
+ * (int64 ids: twice the counts). */
 int dlrm_comm_all_to_all(dlrm_comm *c, const float *d_send, const int64_t *h_send_counts, float *d_recv,
                          const int64_t *h_recv_counts, dlrm_stream_t stream);
 /* d_recv[i] = sum over ranks of their d_send[rank * recv_count + i]. */

@@ -170,8 +170,22 @@ def copy_2d_(dst, src):
     return dst
 
 
+def ids_regroup(recv, world, local_batch, n_tables, hot_offsets=None, offset_base=0, indices=None, offsets=None):
+    from oracle import criteo_oracle
+    hot = [1] * n_tables if hot_offsets is None else list(np.diff(_np(hot_offsets)))
+    idx, off = criteo_oracle.regroup(_np(recv), world, local_batch, hot, offset_base)
+    idx_t, off_t = torch.from_numpy(idx.astype(_np(recv).dtype)), torch.from_numpy(off.astype(_np(recv).dtype))
+    if indices is not None:
+        indices[:idx_t.numel()].copy_(idx_t)
+        idx_t = indices
+    if offsets is not None:
+        offsets[:off_t.numel()].copy_(off_t)
+        off_t = offsets
+    return idx_t, off_t
+
+
 def install(ops_module):
     for name in ("table_init_uniform_", "embbag_forward", "embbag_backward_update", "linear_forward",
                  "linear_backward_data", "linear_backward_weight", "sgd_step_", "interact_dot_forward",
-                 "interact_dot_backward", "loss_mse", "loss_bce_logits", "copy_2d_"):
+                 "interact_dot_backward", "loss_mse", "loss_bce_logits", "copy_2d_", "ids_regroup"):
         setattr(ops_module, name, globals()[name])

@@ -1,6 +1,7 @@
-"""Criteo binary reader: the device decode (dlrm_criteo_decode) against its numpy restatement on a
-synthetic file in the MLPerf-DLRM record layout (no dataset ships with the reference; the record layout
-is the public one: int32 label, 13 int32 counters, 26 int32 hashed ids).  Integer outputs bit-exact,
+"""Criteo binary reader: the device decode (dlrm_criteo_decode) and the regrouping of exchanged ids
+(dlrm_ids_regroup) against their numpy restatements (oracle/criteo_oracle.py; parity unpinned: the reference
+has no reader and no multi-process run) on synthetic files in the MLPerf-DLRM record layout (int32 label, 13
+int32 counters, 26 int32 hashed ids; multi-hot: a fixed number of ids per table).  Integer outputs bit-exact,
 log-transformed dense features to 1e-6 relative."""
 import numpy as np
 import pytest
@@ -9,17 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def decode_reference(records, n_dense, n_sparse, table_rows=None):
-    """numpy restatement of dlrm_criteo_decode: label, log(1 + max(x, 0)) dense block, ids as unsigned modulo the
-    table's rows, table-major with one id per bag."""
-    rec = np.asarray(records, dtype=np.int32).reshape(-1, 1 + n_dense + n_sparse)
-    n = rec.shape[0]
-    labels = rec[:, 0].astype(np.float32)
-    dense = np.log1p(np.maximum(rec[:, 1:1 + n_dense], 0).astype(np.float32)).astype(np.float32)
-    ids = rec[:, 1 + n_dense:].astype(np.uint32).astype(np.int64)
-    if table_rows is not None:
-        ids = ids % np.asarray(table_rows, dtype=np.int64)[None, :]
-    return dense, labels, ids.T.reshape(-1).copy(), np.arange(n_sparse * n + 1, dtype=np.int64)
+def decode_reference(records, n_dense, n_sparse, table_rows=None, table_order=None, hotness=None):
+    from oracle import criteo_oracle
+    return criteo_oracle.decode(records, n_dense, n_sparse, table_rows, table_order, hotness)
 
 
 @pytest.mark.parametrize("idx_t", [torch.int32, torch.int64])
@@ -66,3 +59,56 @@ def test_reader_feeds_a_train_step(tmp_path):
         m.load_batch(dense, labels)
         losses.append(m.train_step(idx, off).item())
     assert int(m.err_flag.item()) == 0 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("idx_t", [torch.int32, torch.int64])
+@pytest.mark.parametrize("B", [1, 100, 300])
+def test_multi_hot_records_in_plan_order(tmp_path, idx_t, B):
+    """Fixed-hotness multi-hot records (tables with 1..7 ids per sample), output tables permuted (a sharding
+    plan's order), two ranks each reading their slice of every global batch."""
+    from dlrm_amd.criteo import CriteoBinReader
+    rng = np.random.default_rng(100 + B)
+    T = 9
+    hot = [int(h) for h in rng.integers(1, 8, T)]
+    hot[3] = 1
+    order = [int(t) for t in rng.permutation(T)]
+    world = 2
+    n = 3 * world * B + B // 2
+    fields = 1 + 13 + sum(hot)
+    rec = np.empty((n, fields), dtype=np.int32)
+    rec[:, 0] = rng.integers(0, 2, n)
+    rec[:, 1:14] = rng.integers(-3, 100000, (n, 13))
+    rec[:, 14:] = rng.integers(0, 2**32, (n, sum(hot)), dtype=np.uint64).astype(np.uint32).view(np.int32)
+    path = tmp_path / "mh.bin"
+    rec.tofile(path)
+    rows = [int(x) for x in rng.integers(1, 10_000_000, T)]
+    for rank in range(world):
+        rd = CriteoBinReader(str(path), B, table_rows=rows, n_sparse=T, idx_dtype=idx_t, hotness=hot, table_order=order,
+                             rank=rank, world=world)
+        assert len(rd) == 3
+        for i in range(4):
+            dense, labels, idx, off = rd.batch(i)
+            torch.cuda.synchronize()
+            first = ((i % 3) * world + rank) * B
+            d_ref, l_ref, i_ref, o_ref = decode_reference(rec[first:first + B], 13, T, rows, order, hot)
+            assert np.array_equal(labels.cpu().numpy(), l_ref)
+            assert np.array_equal(idx.cpu().numpy().astype(np.int64), i_ref)
+            assert np.array_equal(off.cpu().numpy().astype(np.int64), o_ref)
+            assert np.allclose(dense.cpu().numpy(), d_ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("idx_t", [torch.int32, torch.int64])
+@pytest.mark.parametrize("world,B,hot", [(1, 37, [1, 1, 1]), (4, 50, [2, 1, 5, 3]), (8, 300, [1] * 4), (3, 1, [4])])
+def test_ids_regroup_matches_restatement(idx_t, world, B, hot):
+    from dlrm_amd import ops
+    from oracle import criteo_oracle
+    rng = np.random.default_rng(world * 1000 + B)
+    recv = rng.integers(0, 2**31 - 1, world * B * sum(hot)).astype(np.int64)
+    hot_off = torch.tensor(np.concatenate([[0], np.cumsum(hot)]), dtype=torch.int32, device="cuda")
+    d_recv = torch.from_numpy(recv).to(idx_t).cuda()
+    for base, ho in ((0, hot_off), (12345, hot_off)) + (((7, None),) if max(hot) == 1 else ()):
+        idx, off = ops.ids_regroup(d_recv, world, B, len(hot), ho, base)
+        torch.cuda.synchronize()
+        i_ref, o_ref = criteo_oracle.regroup(recv, world, B, hot, base)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), i_ref)
+        assert np.array_equal(off.cpu().numpy().astype(np.int64), o_ref)

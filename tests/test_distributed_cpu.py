@@ -134,6 +134,13 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False, backend="g
             idx_l = np.concatenate([idx[t * Bg * L:(t + 1) * Bg * L] for t in my]) if my else np.zeros(0, np.int64)
             off_l = np.arange(len(my) * Bg + 1, dtype=np.int64) * L
             sl = slice(rank * Bl, (rank + 1) * Bl)
+            # the index exchange: from this rank's slice of the batch (all tables, plan order) to the ids of
+            # its tables for the global batch -- must equal the direct construction above, bit for bit
+            loc = np.concatenate([idx[t * Bg * L + rank * Bl * L:t * Bg * L + (rank + 1) * Bl * L]
+                                  for t in m.plan.feature_order])
+            x_idx, x_off = m.exchange_ids(torch.from_numpy(loc).to(dev))
+            if not (np.array_equal(host(x_idx), idx_l) and np.array_equal(host(x_off), off_l)):
+                bad.append("index exchange step %d" % step)
             m.load_batch(torch.from_numpy(dense[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev))
             loss = m.train_step(torch.from_numpy(idx_l).to(dev), torch.from_numpy(off_l).to(dev))
             tot = loss.detach().clone() if backend == "nccl" else loss.detach().cpu().clone()
