@@ -472,6 +472,25 @@ struct Net2 {
     }
     // create_fc binds global randn weights (src/dlrmtest.cpp:110-140); here the caller supplies them
     void set_layer(int i, const std::vector<float> &w, const std::vector<float> &bias) { W[i].upload(w); b[i].upload(bias); }
+    // Net2::forward(x, y) (src/dlrmtest.cpp:254-272): fc1, fc2 on the dense features, torch::cat with the pooled
+    // embeddings, fc3, fc4, ReLU after every layer.  x: [B, dense] device floats; `pooled` writes the EmbeddingBag
+    // outputs in place of the concatenation: it is called with (buffer, row stride, first column) and must fill
+    // columns [32, 32 + T*D) of every row -- emb::forward does exactly that, so
+    //     net2.forward(d_x, B, [&](float *cat, int64_t ld, int col0) { embedding.forward(cat, ld, col0); })
+    // is the reference's  net2->forward(dense, embedding->forward(...))  without the copy.  Returns the [B]
+    // predictions (device).  The activations stay available for the backward pass (h1, cat, h3, pred).
+    template <class Pooled>
+    const float *forward(const float *x, int batch, Pooled &&pooled) {
+        h1.resize((size_t)batch * 128); catbuf.resize((size_t)batch * cat); h3.resize((size_t)batch * 32); pred.resize(batch);
+        linear(x, dense, W[0].p, dense, b[0].p, h1.p, 128, batch, 128, dense);
+        linear(h1.p, 128, W[1].p, 128, b[1].p, catbuf.p, cat, batch, 32, 128);
+        pooled(catbuf.p, (int64_t)cat, 32);
+        linear(catbuf.p, cat, W[2].p, cat, b[2].p, h3.p, 32, batch, 32, cat);
+        linear(h3.p, 32, W[3].p, 32, b[3].p, pred.p, 1, batch, 1, 32);
+        return pred.p;
+    }
+    DeviceArray<float> h1, catbuf, h3, pred;
+
     static void linear(const float *x, int64_t x_ld, const float *w, int64_t w_ld, const float *bias, float *y, int64_t y_ld,
                        int64_t M, int N, int K) {
         dlrm_linear l{};

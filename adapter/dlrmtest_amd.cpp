@@ -202,8 +202,9 @@ static int train(Options o) {
         emb_cache.write();
 
         const int row = m.dense + m.T * m.L, cat = net2.cat, bb = batch_size;
-        DeviceArray<float> d_x((size_t)bb * m.dense), d_t(bb), h1((size_t)bb * 128), catbuf((size_t)bb * cat), h3((size_t)bb * 32),
-            pred(bb), dpred(bb), dz3((size_t)bb * 32), dcat((size_t)bb * cat), dz2((size_t)bb * 32), dz1((size_t)bb * 128), loss(1);
+        DeviceArray<float> d_x((size_t)bb * m.dense), d_t(bb), dpred(bb), dz3((size_t)bb * 32), dcat((size_t)bb * cat),
+            dz2((size_t)bb * 32), dz1((size_t)bb * 128), loss(1);
+        DeviceArray<float> &h1 = net2.h1, &catbuf = net2.catbuf, &h3 = net2.h3, &pred = net2.pred;
         DeviceArray<float> dW[4], db[4];
         DeviceArray<char> ws, ws_dense;
         const int N_[4] = {128, 32, 32, 1}, K_[4] = {m.dense, 128, cat, 32};
@@ -249,12 +250,8 @@ static int train(Options o) {
                 d_x.upload(xd);
                 d_t.upload(in.target.data() + s0, B);
 
-                // Net2::forward (:254-272)
-                Net2::linear(d_x.p, m.dense, net2.W[0].p, m.dense, net2.b[0].p, h1.p, 128, B, 128, m.dense);
-                Net2::linear(h1.p, 128, net2.W[1].p, 128, net2.b[1].p, catbuf.p, cat, B, 32, 128);
-                embedding.forward(catbuf.p, cat, 32);   // torch::cat({x, y}, 1) without the copy
-                Net2::linear(catbuf.p, cat, net2.W[2].p, cat, net2.b[2].p, h3.p, 32, B, 32, cat);
-                Net2::linear(h3.p, 32, net2.W[3].p, 32, net2.b[3].p, pred.p, 1, B, 1, 32);
+                // net2->forward(dense, embedding->forward(lookup)) (:514-518, :254-272)
+                net2.forward(d_x.p, B, [&](float *catp, int64_t ld, int col0) { embedding.forward(catp, ld, col0); });
                 check(dlrm_loss_mse(pred.p, d_t.p, B, B, loss.p, dpred.p, 1, nullptr), "dlrm_loss_mse");   // :522
 
                 // loss.backward() (:531) down to the pooled embeddings

@@ -10,10 +10,16 @@ embeddings exchanged with RCCL all-to-all, MLP gradients all-reduced -- strong
 scaling.  A step = forward, loss, backward, fused sparse row update and dense
 SGD step on synthetic data already resident in HBM.
 
-Rank 0 prints one JSON line (see README/DESIGN for the fields).  `roofline`
-describes the kernel class that takes the most time in the timed region,
-`kernels` lists every class; durations come from HIP events recorded around
-the launches inside the timed steps.
+Rank 0 prints one JSON line (see README/DESIGN for the fields).
+
+Host of the step (--host): "c" (default) = the step lives in libdlrm_amd.so behind dlrm_model_* (placement,
+streams, exchanges over dlrm_comm / RCCL, operator order: csrc/model.hip), this script only feeds batches -- what
+a C++ host runs (adapter/dlrm_train.cpp is the same loop without Python).  `roofline` then describes the operator
+class that takes the most time per step, timed with HIP events around its launches INSIDE the timed steps (on
+the streams they run on); `kernels` lists every class, timed the same way in a few extra steps after the timed
+region (events around all ~60 launches of a step cost throughput, so they stay out of the timed steps).
+"python" = dlrm_amd.model (the recorded step replayed through dlrm_plan_run, or --eager); needed for the cached
+modes; every class is timed inside the timed steps there.
 """
 import argparse
 import json
@@ -156,6 +162,252 @@ KERNEL_OF = {
 }
 
 
+
+def run_cpu_baseline(cfg):
+    """The same operator sequence on libtorch's CPU kernels (oracle/cpu_baseline.py, kind "port"), timed on this
+    box's host cores on a bounded sample of the workload: all cores, and one thread."""
+    from oracle.cpu_baseline import time_cpu_baseline
+    return time_cpu_baseline(cfg, batch=2048 if cfg.name == "criteo-kaggle" else 65536)
+
+
+def layer_shapes(cfg):
+    bsz = [cfg.dense_in] + list(cfg.bottom)
+    tsz = [cfg.top_in] + list(cfg.top)
+    return list(zip(bsz[:-1], bsz[1:])), list(zip(tsz[:-1], tsz[1:]))
+
+
+def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz):
+    """Algorithmic work of one step on one rank per operator class: (work, "mfma" flops | "hbm" bytes)."""
+    skinny = lambda K, N: (K <= 16 and N >= 64) or N == 1
+    w = {k: 0.0 for k in ("linear_forward", "linear_backward_data", "linear_backward_weight", "linear_forward_skinny",
+                          "linear_backward_data_skinny", "linear_backward_weight_skinny")}
+    bot, top = layer_shapes(cfg)
+    for stack, layers in (("bot", bot), ("top", top)):
+        for i, (K, N) in enumerate(layers):
+            if skinny(K, N):
+                w["linear_forward_skinny"] += 4.0 * B * (N + K)
+                w["linear_backward_weight_skinny"] += 4.0 * B * (N + K)
+            else:
+                w["linear_forward"] += 2.0 * B * N * K
+                w["linear_backward_weight"] += 2.0 * B * N * K
+            has_dgrad = i > 0 or stack == "top"      # the bottom MLP's first layer needs no input gradient
+            if has_dgrad:
+                masked = not (stack == "top" and i == 0)
+                if N == 1:
+                    w["linear_backward_data_skinny"] += 4.0 * B * (N + K * (2 if masked else 1))
+                else:
+                    w["linear_backward_data"] += 2.0 * B * N * K
+    D, L = cfg.dim, cfg.lookups
+    n_tw, n_rw = Bg * Tl * L, Bg * Trw * L
+    out = {k: (v, "hbm" if k.endswith("_skinny") else "mfma") for k, v in w.items() if v}
+    out["embbag_forward"] = ((n_tw + n_rw / world) * D * row_esz + Bg * (Tl + Trw) * D * 4 + (n_tw + n_rw) * idx_esz +
+                             (Bg * (Tl + Trw) + 1) * idx_esz, "hbm")
+    out["embbag_backward_update"] = (Bg * (Tl + Trw) * D * 4 + 2 * (uniq + uniq_rw) * D * row_esz + (n_tw + n_rw) * idx_esz, "hbm")
+    out["embbag_backward_prepare"] = (0.0, "hbm")
+    if cfg.interaction == "dot":
+        F = cfg.num_features
+        out["interact_dot_forward"] = (B * (F * D + D + F * (F - 1) // 2) * 4, "hbm")
+        out["interact_dot_backward"] = (B * (2 * F * D + D + F * (F - 1) // 2) * 4, "hbm")
+    return out
+
+
+def kernel_rows(timing, work, steps, gemm_name, gemm_peak):
+    """timing: {class: (ms summed, launches)} over `steps` steps -> the `kernels` rows of the bench line."""
+    rows = []
+    for name, (ms, launches) in timing.items():
+        wk, kind = work.get(name, (0.0, "hbm"))
+        sec = ms * 1e-3
+        ach = wk * steps / sec if sec > 0 else 0.0
+        peak = gemm_peak if kind == "mfma" else HBM_PEAK
+        kname = KERNEL_OF.get(name, name)
+        if kind == "mfma":
+            kname = kname % gemm_name
+        rows.append({"op": name, "kernel": kname, "bound": kind, "achieved": ach / 1e12, "peak": peak / 1e12,
+                     "unit": "TFLOP/s" if kind == "mfma" else "TB/s", "frac": ach / peak, "ms_per_step": ms / steps,
+                     "launches_per_step": launches / steps, "avg_launch_ms": ms / max(launches, 1)})
+    rows.sort(key=lambda k: -k["ms_per_step"])
+    return rows
+
+
+def roofline_of(dom, gemm_mode, traffic):
+    r = {"kernel": dom["kernel"], "bound": dom["bound"],
+         "achieved": dom["achieved"] * (1e3 if dom["bound"] == "hbm" else 1.0),
+         "peak": dom["peak"] * (1e3 if dom["bound"] == "hbm" else 1.0),
+         "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
+         "avg_launch_ms": dom["avg_launch_ms"], "traffic": traffic.get(dom["op"]) if traffic else None}
+    if dom["bound"] == "mfma":
+        r["peak_note"] = ("float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6"
+                          if gemm_mode == 1 else "float32 MFMA dense peak")
+        r["mfma_tflops_executed"] = dom["achieved"] * (6.0 if gemm_mode == 1 else 1.0)
+    return r
+
+
+def load_traffic(world):
+    """HBM bytes per operator launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)."""
+    for name in ("round2_hbm_traffic.json", "round1_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if world == 1 and os.path.exists(tpath):
+            return json.load(open(tpath)).get("per_op_bytes_per_launch", {})
+    return {}
+
+
+def run_c_host(args, cfg, Bg, B, rank, world, dev):
+    """The step hosted inside libdlrm_amd.so (dlrm_model_*); exchanges over dlrm_comm (RCCL)."""
+    import torch.distributed as dist
+    from dlrm_amd import comm as dcomm
+    from dlrm_amd import ops
+    from dlrm_amd.cmodel import CModel
+    from dlrm_amd.data import synthetic_batch
+    gemm_mode = ops.get_gemm_mode()
+    gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
+    cm, owner = None, None
+    if world > 1:
+        ids = [dcomm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        cm = dcomm.Comm(ids[0], rank, world)
+        if args.sharding == "hybrid":
+            from dlrm_amd.sharding import plan_hybrid
+            owner = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows).owner
+    model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
+                   overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
+                   wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
+                   gemm_mode=2 if gemm_mode == 1 else 1)
+    model.init_dense(0)
+    Tl = model.info.num_whole_tables
+    Trw = model.info.num_local_tables - Tl
+    local_rows = [cfg.table_rows[g] for g, _, _, _ in model.local_tables]
+    n_batches = args.batches or 4
+    batches = []
+    for i in range(n_batches):
+        dense, idx, off, labels = synthetic_batch(local_rows, Bg, cfg.lookups, cfg.dense_in, dev, seed=1000 * (i + 1) + rank,
+                                                  loss=cfg.loss, dist=args.dist, local_batch=B, shared_from=Tl,
+                                                  shared_seed=77 * (i + 1))
+        uniq, uniq_rw, n_per = 0, 0, Bg * cfg.lookups
+        for lt, (g, _, rows, lo) in enumerate(model.local_tables):
+            u = torch.unique(idx[lt * n_per:(lt + 1) * n_per])
+            if lt < Tl:
+                uniq += int(u.numel())
+            else:
+                uniq_rw += int(((u >= lo) & (u < lo + rows)).sum().item())
+        batches.append((dense.contiguous(), idx, off, labels, (uniq, uniq_rw)))
+
+    def step(i):
+        dense, idx, off, labels, _ = batches[i % n_batches]
+        model.load_batch(dense, labels)
+        return model.train_step(idx, off)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def work_for(step_ids):
+        u = sum(batches[i % n_batches][4][0] for i in step_ids) / max(len(step_ids), 1)
+        ur = sum(batches[i % n_batches][4][1] for i in step_ids) / max(len(step_ids), 1)
+        return step_work(cfg, B, Bg, world, Tl, Trw, u, ur, 4, 2 if cfg.row_dtype == "bf16" else 4)
+
+    launches_per_step = 80
+    # warm-up; its last steps time every class to find the one that dominates a step
+    n_probe = min(2, args.warmup)
+    for i in range(args.warmup - n_probe):
+        step(i)
+    model.enable_timing("all", launches_per_step * max(n_probe, 1))
+    for i in range(args.warmup - n_probe, args.warmup):
+        step(i)
+    probe = model.collect_timing()
+    timed_cls = [k for k, _ in sorted(probe.items(), key=lambda kv: -kv[1][0]) if k != "embbag_backward_prepare"][:1] \
+        or ["linear_backward_data"]
+    model.enable_timing(timed_cls, 16 * args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int(model.err_flag.item()) != 0:
+        raise SystemExit("out-of-range embedding index reported by the kernels")
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt * 1e3 / args.steps
+    value = Bg * args.steps / dt
+    loss_value = float(loss.item())
+    timed_ids = [args.warmup + i for i in range(args.steps)]
+    dom_rows = kernel_rows(model.collect_timing(), work_for(timed_ids), args.steps, gemm_name, gemm_peak)
+    traffic = load_traffic(world)
+    roofline = roofline_of(dom_rows[0], gemm_mode, traffic) if dom_rows else None
+    if roofline:
+        roofline["timed"] = "HIP events around this operator's launches inside the timed steps"
+
+    # every class, in extra steps after the timed region
+    n_k = max(min(args.steps, 10), 1)
+    model.enable_timing("all", launches_per_step * n_k)
+    k_ids = [args.warmup + args.steps + i for i in range(n_k)]
+    for i in k_ids:
+        step(i)
+    kernels = kernel_rows(model.collect_timing(), work_for(k_ids), n_k, gemm_name, gemm_peak)
+    for k in kernels:
+        k["traffic"] = traffic.get(k["op"]) if traffic else None
+    model.enable_timing([], 0)
+    emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
+
+    # forward only (inference), same batches
+    n_inf = max(min(args.steps, 10), 1)
+    for i in range(2):
+        model.forward(batches[i % n_batches][1], batches[i % n_batches][2])
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(n_inf):
+        dense, idx, off, labels, _ = batches[i % n_batches]
+        model.load_batch(dense, labels)
+        model.forward(idx, off)
+    torch.cuda.synchronize()
+    barrier()
+    dt_inf = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_inf = float(tt.item())
+    infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
+             "launch": "dlrm_model_forward"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(cfg)
+    if rank == 0:
+        line = {
+            "metric": "train samples/s (node) MLPerf-DLRM shape @1/2/4/8 GPU; EmbBag HBM GB/s",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (%s ids, random-init weights)" % args.dist,
+            "config": {"workload": cfg.name, "global_batch": Bg, "tables": cfg.num_tables, "dim": cfg.dim,
+                       "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
+                       "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
+                       "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
+                       "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
+                       if gemm_mode == 1 else "float32 MFMA",
+                       "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)",
+                       "parallelism": "single GPU" if world == 1 else
+                       ("%s x%d + data-parallel MLP" % ("table-wise" if not Trw else
+                                                        "table-wise + %d row-wise tables" % Trw, world))},
+            "loss": loss_value, "cache": None, "inference": infer, "roofline": roofline,
+            "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,
+            "kernels": kernels, "kernels_timed": "every class, in %d extra steps after the timed region" % n_k,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    model.close()
+    if cm is not None:
+        cm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +429,9 @@ def main():
                          "pages (the reference's second policy)")
     ap.add_argument("--no-prefetch", action="store_true", help="cached mode: look ids up inside the step")
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches to cycle (default 4; 64 cached)")
+    ap.add_argument("--host", default="auto", choices=["auto", "c", "python"],
+                    help="who hosts the step: c = dlrm_model_* inside the library (default unless a cache is asked for), "
+                         "python = dlrm_amd.model")
     ap.add_argument("--eager", action="store_true",
                     help="launch every operator from Python instead of replaying the recorded step (dlrm_plan)")
     ap.add_argument("--replay", action="store_true", help="(default) replay the recorded step")
@@ -231,6 +486,13 @@ def main():
         Bg = 2048
     assert Bg % world == 0
     B = Bg // world
+    host = args.host
+    if host == "auto":
+        host = "python" if (args.cache_fraction > 0 or args.eager) else "c"
+    if host == "c":
+        if args.cache_fraction > 0:
+            raise SystemExit("the cached modes are hosted by dlrm_amd.model: --host python")
+        return run_c_host(args, cfg, Bg, B, rank, world, dev)
     model_ref = {"unique_rows": 0, "unique_rows_rw": 0, "lookups": cfg.lookups, "world": world}
     timer = install_timers(ops, model_ref)
     gemm_mode = ops.get_gemm_mode()   # 1: float32 products as six bf16 MFMA terms; 0: float32 MFMA
@@ -414,8 +676,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.cpu_baseline import time_cpu_baseline
-        cpu_baseline = time_cpu_baseline(cfg, batch=8192, table_rows_cap=200000, warmup=1, steps=5)
+        cpu_baseline = run_cpu_baseline(cfg)
 
     if rank == 0:
         line = {

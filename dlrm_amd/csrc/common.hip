@@ -21,8 +21,10 @@ int set_error(int code, const char *fmt, ...) {
 template <typename T>
 __global__ void table_init_uniform_kernel(T *dst, int64_t n, uint64_t seed, int64_t first) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the seed is hashed first: streams of nearby seeds (one per table) are unrelated, not shifted copies
+    const uint64_t base = splitmix64(seed);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = (float)(splitmix64(seed + (uint64_t)(first + i)) >> 40) * (1.0f / 16777216.0f);
+        const float v = (float)(splitmix64(base + (uint64_t)(first + i)) >> 40) * (1.0f / 16777216.0f);
         if constexpr (sizeof(T) == 4)
             dst[i] = v;
         else

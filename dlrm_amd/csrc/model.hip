@@ -1,0 +1,745 @@
+// The whole DLRM train / inference step behind one handle, for hosts without a Python runtime: the C++ host of
+// the training loop of dlrm_libtorch/src/dlrmtest.cpp (main(), :473-545) at the Criteo shapes -- EmbeddingBags
+// over every table (struct emb, :144-210), bottom MLP, dot or concat interaction, top MLP (struct Net2,
+// :217-278), loss, backward, SGD on the dense parameters, fused sparse update of the rows (:505-535).
+//
+// Host code only: every computation is one of the library's own C-ABI operators, launched on up to four
+// streams -- the caller's ("main"), "emb" (EmbeddingBag kernels and their exchanges beside the bottom MLP),
+// "prep" (the sparse update's sort, which needs the ids only, beside the forward pass) and "wgrad" (weight
+// gradients beside the chain of data gradients at small batches).
+//
+// Sharded over the ranks of a dlrm_comm (one process per GPU, RCCL): every rank looks its tables up for the
+// GLOBAL batch.  Whole tables: pooled vectors go to the rank that owns each batch slice with one all-to-all,
+// their gradients come back with another.  Row-wise split tables: every rank pools the rows of its range, a
+// reduce-scatter over the batch adds the partial sums, an all-gather brings the gradients of the global batch
+// back.  The MLPs are data parallel (one all-reduce of the flat gradient buffer); losses are means over the
+// global batch, so per-rank gradients add.  The reference is one process; the layout follows its striping of
+// tables over parallel units (include/data2.h:150, src/emb_cache2.cpp:701-709).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace dlrm {
+
+static int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
+// leading dimension of a matrix whose columns are a GEMM reduction / output index: wide ones are whole
+// 128-column tiles, so that every tile can use 16-byte loads (the pad columns are zero and never stored to)
+static int64_t padk(int64_t n) { return n <= 128 ? pad4(n) : (n + 127) / 128 * 128; }
+
+struct Layer {
+    int N, K;
+    int64_t w_off, w_ld, b_off;   // offsets into the flat parameter / gradient buffers
+};
+
+struct Act {   // a [B, n] activation: pointer + leading dimension
+    float *p = nullptr;
+    int64_t ld = 0;
+};
+
+}  // namespace dlrm
+
+using namespace dlrm;
+
+struct dlrm_model {
+    dlrm_model_config cfg;
+    std::vector<int64_t> table_rows;
+    std::vector<int> bottom, top, owner;
+    int T, D, F, B, world, rank;
+    int64_t Bg;
+    bool sharded, dot;
+    // placement
+    std::vector<int> my_tables, rw_tables, feature_order;
+    std::vector<std::vector<int>> tables_of_rank;
+    std::vector<int64_t> local_rows, tro, shard_begin_h;
+    int Tl, Trw, n_tw;
+    int64_t total_rows;
+    // device memory
+    std::vector<void *> allocs;
+    void *weight = nullptr;
+    float *opt_state = nullptr;
+    int64_t *d_tro = nullptr, *d_shard_begin = nullptr;
+    int32_t *err_flag = nullptr;
+    float *params = nullptr, *grads = nullptr;
+    int64_t n_params = 0;
+    std::vector<Layer> bot, topl;
+    float *x_dense = nullptr, *labels = nullptr, *feat = nullptr, *dfeat = nullptr, *inter = nullptr, *dinter = nullptr;
+    int64_t x_ld = 0, feat_ld = 0, inter_ld = 0;
+    int emb_col0 = 0, top_in = 0;
+    std::vector<Act> bot_acts, bot_dz, top_acts, top_dz;
+    float *pred = nullptr, *dpred = nullptr, *loss = nullptr;
+    void *ws_dense = nullptr, *ws_sparse = nullptr, *ws_sparse_rw = nullptr;
+    size_t ws_dense_bytes = 0, ws_sparse_bytes = 0, ws_sparse_rw_bytes = 0;
+    float *a2a_send = nullptr, *a2a_recv = nullptr, *g_send = nullptr, *g_recv = nullptr, *rw_part = nullptr, *rw_local = nullptr;
+    std::vector<int64_t> send_counts, recv_counts;
+    // streams
+    hipStream_t s_emb = nullptr, s_prep = nullptr, s_wgrad = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t next_event = 0;
+    // optional timing of operator classes: event pairs around the launches, on the launch stream
+    struct TimeRec { int cls; hipEvent_t e0, e1; };
+    std::vector<TimeRec> trecs;
+    size_t n_trecs = 0;
+    uint32_t time_mask = 0;
+};
+
+namespace dlrm {
+
+template <typename T>
+static int dalloc(dlrm_model *m, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    DLRM_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+    m->allocs.push_back(q);
+    if (zero) DLRM_HIP(hipMemset(q, 0, sizeof(T) * (count ? count : 1)));
+    *p = static_cast<T *>(q);
+    return DLRM_OK;
+}
+
+// stream a waits for everything queued on stream b so far
+static int wait_for(dlrm_model *m, hipStream_t a, hipStream_t b) {
+    if (a == b) return DLRM_OK;
+    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+    DLRM_HIP(hipEventRecord(e, b));
+    DLRM_HIP(hipStreamWaitEvent(a, e, 0));
+    return DLRM_OK;
+}
+
+// runs `fn` (one operator call on stream s); when its class is being timed, between two events on s
+template <typename F>
+static int timed(dlrm_model *m, int cls, hipStream_t s, F &&fn) {
+    if (!(m->time_mask & (1u << cls)) || m->n_trecs >= m->trecs.size()) return fn();
+    dlrm_model::TimeRec &r = m->trecs[m->n_trecs++];
+    r.cls = cls;
+    DLRM_HIP(hipEventRecord(r.e0, s));
+    const int rc = fn();
+    DLRM_HIP(hipEventRecord(r.e1, s));
+    return rc;
+}
+
+static bool skinny_shape(int N, int K) { return (K <= 16 && N >= 64) || N == 1; }
+
+static void build_stack(const std::vector<int> &sizes, int64_t &off, std::vector<Layer> &out) {
+    for (size_t i = 0; i + 1 < sizes.size(); i++) {
+        Layer l;
+        l.K = sizes[i]; l.N = sizes[i + 1];
+        l.w_ld = padk(l.K);
+        l.w_off = off; off += (int64_t)l.N * l.w_ld;
+        l.b_off = off; off += pad4(l.N);
+        out.push_back(l);
+    }
+}
+
+static dlrm_embbag table_desc(const dlrm_model *m, bool rw, const void *d_indices, const void *d_offsets, int64_t n_indices) {
+    dlrm_embbag e{};
+    const int esz = m->cfg.idx_dtype == DLRM_I64 ? 8 : 4;
+    e.d_weight = m->weight;
+    e.total_rows = m->total_rows > 0 ? m->total_rows : 1;
+    e.dim = m->D; e.row_dtype = m->cfg.row_dtype; e.idx_dtype = m->cfg.idx_dtype;
+    e.d_indices = d_indices; e.n_indices = n_indices; e.batch = m->Bg;
+    e.include_last_offset = 1; e.pooling = m->cfg.pooling; e.d_error_flag = m->err_flag;
+    if (!rw) {
+        e.num_tables = m->Tl; e.d_table_row_offsets = m->d_tro; e.d_offsets = d_offsets;
+    } else {
+        e.num_tables = m->Trw; e.d_table_row_offsets = m->d_tro + m->Tl;
+        e.d_offsets = static_cast<const char *>(d_offsets) + (int64_t)m->Tl * m->Bg * esz;
+        e.d_shard_row_begin = m->d_shard_begin;
+    }
+    return e;
+}
+
+static int linear_fwd(const dlrm_model *m, const Layer &l, const float *x, int64_t x_ld, float *y, int64_t y_ld, bool relu,
+                      hipStream_t s) {
+    dlrm_linear d{};
+    d.M = m->B; d.N = l.N; d.K = l.K; d.d_x = x; d.x_ld = x_ld; d.d_w = m->params + l.w_off; d.w_ld = l.w_ld;
+    d.d_bias = m->params + l.b_off; d.d_y = y; d.y_ld = y_ld; d.act = relu ? DLRM_ACT_RELU : DLRM_ACT_NONE;
+    d.gemm_mode = m->cfg.gemm_mode;
+    return timed(const_cast<dlrm_model *>(m), skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_FORWARD_SKINNY : DLRM_TIME_LINEAR_FORWARD, s,
+                 [&] { return dlrm_linear_forward(&d, s); });
+}
+
+static int linear_dgrad(const dlrm_model *m, const Layer &l, int64_t col0, int K, const float *dz, int64_t dz_ld, float *dx,
+                        int64_t dx_ld, const float *mask, int64_t mask_ld, hipStream_t s) {
+    dlrm_linear_bwd d{};
+    d.M = m->B; d.N = l.N; d.K = K; d.d_dz = dz; d.dz_ld = dz_ld; d.d_w = m->params + l.w_off + col0; d.w_ld = l.w_ld;
+    d.d_dx = dx; d.dx_ld = dx_ld; d.d_relu_mask = mask; d.relu_mask_ld = mask_ld; d.gemm_mode = m->cfg.gemm_mode;
+    return timed(const_cast<dlrm_model *>(m), l.N == 1 ? DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY : DLRM_TIME_LINEAR_BACKWARD_DATA, s,
+                 [&] { return dlrm_linear_backward_data(&d, s); });
+}
+
+static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, hipStream_t s) {
+    dlrm_linear_bwd d{};
+    d.M = m->B; d.N = l.N; d.K = l.K; d.d_dz = dz; d.dz_ld = dz_ld; d.d_x = x; d.x_ld = x_ld;
+    d.d_dw = m->grads + l.w_off; d.dw_ld = l.w_ld; d.d_db = m->grads + l.b_off; d.gemm_mode = m->cfg.gemm_mode;
+    return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY : DLRM_TIME_LINEAR_BACKWARD_WEIGHT, s,
+                 [&] { return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s); });
+}
+
+// Backward of one MLP stack (MLPStack.backward): the weight gradient of every layer goes to the wgrad stream
+// (it needs the layer's dz only), the chain of data gradients stays on `s`.
+static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const float *x_in, int64_t x_in_ld,
+                          const std::vector<Act> &acts, const float *dz_last, int64_t dz_last_ld, const std::vector<Act> &dz_bufs,
+                          float *dx_first, int64_t dx_first_ld, hipStream_t s) {
+    const int n = (int)st.size();
+    hipStream_t sw = m->s_wgrad ? m->s_wgrad : s;
+    for (int i = n - 1; i >= 0; i--) {
+        const float *dz = i == n - 1 ? dz_last : dz_bufs[i].p;
+        const int64_t dz_ld = i == n - 1 ? dz_last_ld : dz_bufs[i].ld;
+        const float *x = i == 0 ? x_in : acts[i - 1].p;
+        const int64_t xl = i == 0 ? x_in_ld : acts[i - 1].ld;
+        if (int rc = wait_for(m, sw, s)) return rc;      // dz of this layer is complete
+        if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw)) return rc;
+        if (i > 0) {
+            if (int rc = linear_dgrad(m, st[i], 0, st[i].K, dz, dz_ld, dz_bufs[i - 1].p, dz_bufs[i - 1].ld, acts[i - 1].p,
+                                      acts[i - 1].ld, s))
+                return rc;
+        } else if (dx_first) {
+            if (int rc = linear_dgrad(m, st[0], 0, st[0].K, dz, dz_ld, dx_first, dx_first_ld, nullptr, 0, s)) return rc;
+        }
+    }
+    return DLRM_OK;
+}
+
+static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, hipStream_t s) {
+    const int D = m->D;
+    const int64_t B = m->B;
+    if (!m->sharded) {
+        dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
+        return timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->feat + m->emb_col0, m->feat_ld, s); });
+    }
+    if (m->Tl) {
+        dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
+        if (int rc = timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->a2a_send, (int64_t)m->Tl * D, s); }))
+            return rc;
+    }
+    if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->a2a_send, m->send_counts.data(), m->a2a_recv, m->recv_counts.data(), s))
+        return rc;
+    int64_t o = 0;
+    int first = 0;
+    for (int j = 0; j < m->world; j++) {
+        const int cnt = (int)m->tables_of_rank[j].size();
+        if (cnt)
+            if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)first * D, m->feat_ld, m->a2a_recv + o, (int64_t)cnt * D, B,
+                                      (int64_t)cnt * D, s))
+                return rc;
+        o += B * cnt * D;
+        first += cnt;
+    }
+    if (m->Trw) {
+        dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
+        if (int rc = timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->rw_part, (int64_t)m->Trw * D, s); }))
+            return rc;
+        if (int rc = dlrm_comm_reduce_scatter_sum(m->cfg.comm, m->rw_part, m->rw_local, B * m->Trw * D, s)) return rc;
+        if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, m->rw_local, (int64_t)m->Trw * D, B,
+                                  (int64_t)m->Trw * D, s))
+            return rc;
+    }
+    return DLRM_OK;
+}
+
+static dlrm_sparse_opt sparse_opt(const dlrm_model *m) {
+    dlrm_sparse_opt o{};
+    o.optimizer = m->cfg.emb_optimizer; o.dup_mode = DLRM_DUP_ACCUMULATE; o.lr = m->cfg.lr; o.eps = m->cfg.eps;
+    o.d_opt_state = m->opt_state;
+    return o;
+}
+
+static int sparse_update(dlrm_model *m, bool rw, const void *idx, const void *off, int64_t n_idx, const float *grad, int64_t grad_ld,
+                         hipStream_t s) {
+    dlrm_embbag e = table_desc(m, rw, idx, off, n_idx);
+    dlrm_sparse_opt o = sparse_opt(m);
+    void *ws = rw ? m->ws_sparse_rw : m->ws_sparse;
+    const size_t wsb = rw ? m->ws_sparse_rw_bytes : m->ws_sparse_bytes;
+    return timed(m, DLRM_TIME_EMBBAG_BACKWARD_UPDATE, s, [&] {
+        if (m->cfg.presort) return dlrm_embbag_backward_apply(&e, grad, grad_ld, &o, ws, wsb, s);
+        return dlrm_embbag_backward_update(&e, grad, grad_ld, &o, ws, wsb, s);
+    });
+}
+
+static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, hipStream_t s) {
+    const int D = m->D;
+    const int64_t B = m->B;
+    if (m->cfg.presort && m->s_prep)
+        if (int rc = wait_for(m, s, m->s_prep)) return rc;
+    if (!m->sharded) return sparse_update(m, false, idx, off, n_idx, m->dfeat + m->emb_col0, m->feat_ld, s);
+    int64_t o = 0;
+    int first = 0;
+    for (int j = 0; j < m->world; j++) {
+        const int cnt = (int)m->tables_of_rank[j].size();
+        if (cnt)
+            if (int rc = dlrm_copy_2d(m->g_send + o, (int64_t)cnt * D, m->dfeat + m->emb_col0 + (int64_t)first * D, m->feat_ld, B,
+                                      (int64_t)cnt * D, s))
+                return rc;
+        o += B * cnt * D;
+        first += cnt;
+    }
+    if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->g_send, m->recv_counts.data(), m->g_recv, m->send_counts.data(), s)) return rc;
+    if (m->Tl)
+        if (int rc = sparse_update(m, false, idx, off, n_idx, m->g_recv, (int64_t)m->Tl * D, s)) return rc;
+    if (m->Trw) {
+        if (int rc = dlrm_copy_2d(m->rw_local, (int64_t)m->Trw * D, m->dfeat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, B,
+                                  (int64_t)m->Trw * D, s))
+            return rc;
+        if (int rc = dlrm_comm_all_gather(m->cfg.comm, m->rw_local, m->rw_part, B * m->Trw * D, s)) return rc;
+        if (int rc = sparse_update(m, true, idx, off, n_idx, m->rw_part, (int64_t)m->Trw * D, s)) return rc;
+    }
+    return DLRM_OK;
+}
+
+static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, bool train, hipStream_t main) {
+    hipStream_t emb = m->s_emb ? m->s_emb : main;
+    if (train && m->cfg.presort) {
+        hipStream_t prep = m->s_prep ? m->s_prep : main;
+        if (int rc = wait_for(m, prep, main)) return rc;
+        if (m->Tl) {
+            dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
+            if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
+                               [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse, m->ws_sparse_bytes, prep); }))
+                return rc;
+        }
+        if (m->Trw && m->sharded) {
+            dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
+            if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
+                               [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse_rw, m->ws_sparse_rw_bytes, prep); }))
+                return rc;
+        }
+    }
+    if (int rc = wait_for(m, emb, main)) return rc;   // earlier readers of feat and the input copies are done
+    if (int rc = emb_forward(m, idx, off, n_idx, emb)) return rc;
+    // bottom MLP on main
+    const float *x = m->x_dense;
+    int64_t xl = m->x_ld;
+    for (size_t i = 0; i < m->bot.size(); i++) {
+        if (int rc = linear_fwd(m, m->bot[i], x, xl, m->bot_acts[i].p, m->bot_acts[i].ld, true, main)) return rc;
+        x = m->bot_acts[i].p; xl = m->bot_acts[i].ld;
+    }
+    if (int rc = wait_for(m, main, emb)) return rc;
+    if (m->dot)
+        if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main,
+                           [&] { return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main); }))
+            return rc;
+    x = m->inter; xl = m->inter_ld;
+    for (size_t i = 0; i < m->topl.size(); i++) {
+        const bool relu = m->cfg.final_relu || i + 1 < m->topl.size();
+        if (int rc = linear_fwd(m, m->topl[i], x, xl, m->top_acts[i].p, m->top_acts[i].ld, relu, main)) return rc;
+        x = m->top_acts[i].p; xl = m->top_acts[i].ld;
+    }
+    return DLRM_OK;
+}
+
+// plan_table_wise of the Python host: biggest table first, to the rank with the fewest lookups so far, ties to
+// the one holding the fewest bytes, then the lower rank
+static void greedy_owner(const int64_t *rows, int T, int world, std::vector<int> &owner) {
+    std::vector<int> order(T);
+    for (int t = 0; t < T; t++) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] > rows[b]; });
+    std::vector<double> mem(world, 0.0), lk(world, 0.0);
+    owner.assign(T, 0);
+    for (int t : order) {
+        int best = 0;
+        for (int r = 1; r < world; r++)
+            if (lk[r] < lk[best] || (lk[r] == lk[best] && mem[r] < mem[best])) best = r;
+        owner[t] = best;
+        mem[best] += (double)rows[t];
+        lk[best] += 1.0;
+    }
+}
+
+}  // namespace dlrm
+
+extern "C" int dlrm_model_destroy(dlrm_model *m) {
+    if (!m) return DLRM_OK;
+    (void)hipDeviceSynchronize();
+    for (void *p : m->allocs) (void)hipFree(p);
+    for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
+    for (auto &r : m->trecs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    if (m->s_emb) (void)hipStreamDestroy(m->s_emb);
+    if (m->s_prep) (void)hipStreamDestroy(m->s_prep);
+    if (m->s_wgrad) (void)hipStreamDestroy(m->s_wgrad);
+    delete m;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
+    DLRM_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+    DLRM_REQUIRE(c->num_tables >= 1 && c->table_rows != nullptr && c->dim >= 1 && c->dense_in >= 1, "bad table / feature sizes");
+    DLRM_REQUIRE(c->n_bottom >= 1 && c->bottom != nullptr && c->n_top >= 1 && c->top != nullptr, "bad MLP description");
+    DLRM_REQUIRE(c->top[c->n_top - 1] == 1, "the top MLP must end in one output");
+    DLRM_REQUIRE(c->local_batch >= 1 && c->local_batch < (1ll << 31), "bad local_batch");
+    DLRM_REQUIRE(c->world >= 1 && c->rank >= 0 && c->rank < c->world, "rank %d of %d", c->rank, c->world);
+    DLRM_REQUIRE(c->interaction == DLRM_INTERACT_DOT || c->interaction == DLRM_INTERACT_CAT, "interaction %d", c->interaction);
+    DLRM_REQUIRE(c->loss == DLRM_LOSS_BCE || c->loss == DLRM_LOSS_MSE, "loss %d", c->loss);
+    DLRM_REQUIRE(c->row_dtype == DLRM_F32 || c->row_dtype == DLRM_BF16, "row_dtype %d", c->row_dtype);
+    DLRM_REQUIRE(c->idx_dtype == DLRM_I32 || c->idx_dtype == DLRM_I64, "idx_dtype %d", c->idx_dtype);
+    DLRM_REQUIRE(c->interaction != DLRM_INTERACT_DOT || c->bottom[c->n_bottom - 1] == c->dim,
+                 "the dot interaction needs the bottom MLP to end in dim outputs");
+    const bool sharded = c->world > 1 || c->force_exchange;
+    DLRM_REQUIRE(!sharded || c->comm != nullptr, "a sharded model needs a communicator");
+
+    dlrm_model *m = new dlrm_model();
+    m->cfg = *c;
+    m->T = c->num_tables; m->D = c->dim; m->F = m->T + 1; m->B = (int)c->local_batch; m->world = c->world; m->rank = c->rank;
+    m->Bg = (int64_t)m->B * m->world;
+    m->sharded = sharded; m->dot = c->interaction == DLRM_INTERACT_DOT;
+    m->table_rows.assign(c->table_rows, c->table_rows + m->T);
+    m->bottom.assign(c->bottom, c->bottom + c->n_bottom);
+    m->top.assign(c->top, c->top + c->n_top);
+    m->cfg.table_rows = nullptr; m->cfg.bottom = nullptr; m->cfg.top = nullptr; m->cfg.table_owner = nullptr;
+    auto fail = [&](int rc) { dlrm_model_destroy(m); return rc; };
+
+    // ---- placement
+    if (c->table_owner) m->owner.assign(c->table_owner, c->table_owner + m->T);
+    else greedy_owner(c->table_rows, m->T, m->world, m->owner);
+    m->tables_of_rank.assign(m->world, {});
+    for (int t = 0; t < m->T; t++) {
+        if (m->owner[t] < -1 || m->owner[t] >= m->world) return fail(set_error(DLRM_ERR_INVALID, "table %d: owner %d", t, m->owner[t]));
+        if (m->owner[t] >= 0) m->tables_of_rank[m->owner[t]].push_back(t);
+        else m->rw_tables.push_back(t);
+    }
+    for (int r = 0; r < m->world; r++)
+        for (int t : m->tables_of_rank[r]) m->feature_order.push_back(t);
+    m->n_tw = (int)m->feature_order.size();
+    for (int t : m->rw_tables) m->feature_order.push_back(t);
+    if (!sharded) {
+        if (!m->rw_tables.empty()) return fail(set_error(DLRM_ERR_INVALID, "row-wise tables need a sharded model"));
+        m->my_tables = m->feature_order;
+    } else {
+        m->my_tables = m->tables_of_rank[m->rank];
+    }
+    m->Tl = (int)m->my_tables.size();
+    m->Trw = (int)m->rw_tables.size();
+    m->tro.push_back(0);
+    for (int t : m->my_tables) { m->local_rows.push_back(m->table_rows[t]); m->shard_begin_h.push_back(0); }
+    for (int t : m->rw_tables) {
+        const int64_t rows = m->table_rows[t];
+        if (rows < m->world) return fail(set_error(DLRM_ERR_INVALID, "row-wise table %d has fewer rows than ranks", t));
+        const int64_t lo = rows * m->rank / m->world, hi = rows * (m->rank + 1) / m->world;
+        m->local_rows.push_back(hi - lo);
+        m->shard_begin_h.push_back(lo);
+    }
+    for (int64_t r : m->local_rows) m->tro.push_back(m->tro.back() + r);
+    m->total_rows = m->tro.back();
+
+    // ---- streams and events
+    if (c->overlap < 0 ? sharded : c->overlap != 0)
+        if (hipStreamCreateWithFlags(&m->s_emb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
+    m->cfg.presort = c->presort != 0;
+    if (m->cfg.presort)
+        if (hipStreamCreateWithFlags(&m->s_prep, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
+    if (c->wgrad_stream < 0 ? c->local_batch <= 32768 : c->wgrad_stream != 0)
+        if (hipStreamCreateWithFlags(&m->s_wgrad, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
+    m->events.resize(64);
+    for (auto &e : m->events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "event"));
+
+    // ---- tables
+    const int esz = c->row_dtype == DLRM_F32 ? 4 : 2;
+    int rc = DLRM_OK;
+    {
+        char *w = nullptr;
+        rc = dalloc(m, &w, (size_t)(m->total_rows > 0 ? m->total_rows : 1) * m->D * esz, false);
+        if (rc) return fail(rc);
+        m->weight = w;
+    }
+    if ((rc = dalloc(m, &m->d_tro, m->tro.size()))) return fail(rc);
+    if (hipMemcpy(m->d_tro, m->tro.data(), sizeof(int64_t) * m->tro.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(set_error(DLRM_ERR_HIP, "copy of the row offsets failed"));
+    if (m->Trw) {
+        if ((rc = dalloc(m, &m->d_shard_begin, (size_t)m->Trw))) return fail(rc);
+        if (hipMemcpy(m->d_shard_begin, m->shard_begin_h.data() + m->Tl, sizeof(int64_t) * m->Trw, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(set_error(DLRM_ERR_HIP, "copy of the shard ranges failed"));
+    }
+    if (c->init_tables)
+        for (int lt = 0; lt < m->Tl + m->Trw; lt++) {
+            // every table is its own stream of uniform [0,1) values keyed by the GLOBAL table id, so a sharded
+            // model holds the same numbers as a single-GPU one
+            const int t = lt < m->Tl ? m->my_tables[lt] : m->rw_tables[lt - m->Tl];
+            rc = dlrm_table_init_uniform(static_cast<char *>(m->weight) + m->tro[lt] * m->D * esz, c->row_dtype,
+                                         m->local_rows[lt] * m->D, (c->seed << 20) + 7919ull * (uint64_t)(t + 1),
+                                         m->shard_begin_h[lt] * m->D, nullptr);
+            if (rc) return fail(rc);
+        }
+    if (c->emb_optimizer == DLRM_OPT_ADAGRAD_ROWWISE)
+        if ((rc = dalloc(m, &m->opt_state, (size_t)(m->total_rows > 0 ? m->total_rows : 1)))) return fail(rc);
+    if ((rc = dalloc(m, &m->err_flag, 1))) return fail(rc);
+
+    // ---- dense parameters: one flat buffer and its twin for the gradients
+    m->top_in = m->dot ? m->D + m->F * (m->F - 1) / 2 : m->bottom.back() + m->T * m->D;
+    std::vector<int> bsz{c->dense_in}, tsz{m->top_in};
+    bsz.insert(bsz.end(), m->bottom.begin(), m->bottom.end());
+    tsz.insert(tsz.end(), m->top.begin(), m->top.end());
+    int64_t off = 0;
+    build_stack(bsz, off, m->bot);
+    build_stack(tsz, off, m->topl);
+    m->n_params = off;
+    if ((rc = dalloc(m, &m->params, (size_t)off))) return fail(rc);
+    if ((rc = dalloc(m, &m->grads, (size_t)off))) return fail(rc);
+
+    // ---- activations
+    const size_t B = (size_t)m->B;
+    m->x_ld = pad4(c->dense_in);
+    if ((rc = dalloc(m, &m->x_dense, B * m->x_ld))) return fail(rc);
+    if ((rc = dalloc(m, &m->labels, B))) return fail(rc);
+    m->inter_ld = padk(m->top_in);
+    if (m->dot) {
+        m->feat_ld = (int64_t)m->F * m->D;
+        m->emb_col0 = m->D;
+        if ((rc = dalloc(m, &m->feat, B * m->feat_ld))) return fail(rc);
+        if ((rc = dalloc(m, &m->dfeat, B * m->feat_ld))) return fail(rc);
+        if ((rc = dalloc(m, &m->inter, B * m->inter_ld))) return fail(rc);
+        if ((rc = dalloc(m, &m->dinter, B * m->inter_ld))) return fail(rc);
+    } else {
+        m->feat_ld = m->inter_ld;
+        m->emb_col0 = m->bottom.back();
+        if ((rc = dalloc(m, &m->feat, B * m->feat_ld))) return fail(rc);
+        if ((rc = dalloc(m, &m->dfeat, B * m->feat_ld))) return fail(rc);
+        m->inter = m->feat; m->dinter = m->dfeat;
+    }
+    auto make_acts = [&](const std::vector<int> &widths, std::vector<Act> &acts, size_t count) {
+        for (size_t i = 0; i < count; i++) {
+            Act a;
+            a.ld = padk(widths[i]);
+            if (int r = dalloc(m, &a.p, B * a.ld)) return r;
+            acts.push_back(a);
+        }
+        return (int)DLRM_OK;
+    };
+    if ((rc = make_acts(m->bottom, m->bot_acts, m->bottom.size() - 1))) return fail(rc);
+    m->bot_acts.push_back(Act{m->feat, m->feat_ld});            // the last bottom layer writes feature 0 / the concat's head
+    if ((rc = make_acts(m->bottom, m->bot_dz, m->bottom.size() - 1))) return fail(rc);
+    if ((rc = make_acts(m->top, m->top_acts, m->top.size() - 1))) return fail(rc);
+    if ((rc = dalloc(m, &m->pred, B))) return fail(rc);
+    m->top_acts.push_back(Act{m->pred, 1});
+    if ((rc = make_acts(m->top, m->top_dz, m->top.size() - 1))) return fail(rc);
+    if ((rc = dalloc(m, &m->dpred, B))) return fail(rc);
+    if ((rc = dalloc(m, &m->loss, 1))) return fail(rc);
+
+    // ---- workspaces: the largest any layer / any batch of the configured shape needs
+    size_t need = 0;
+    for (const auto *st : {&m->bot, &m->topl})
+        for (const Layer &l : *st) {
+            size_t b = 0;
+            if ((rc = dlrm_linear_backward_weight_workspace_bytes(m->B, l.N, l.K, &b))) return fail(rc);
+            if (b > need) need = b;
+        }
+    m->ws_dense_bytes = need;
+    {
+        char *p = nullptr;
+        if ((rc = dalloc(m, &p, need, false))) return fail(rc);
+        m->ws_dense = p;
+    }
+
+    // ---- exchange buffers
+    if (sharded) {
+        const int64_t D = m->D;
+        m->send_counts.assign(m->world, (int64_t)m->B * m->Tl * D);
+        for (int j = 0; j < m->world; j++) m->recv_counts.push_back((int64_t)m->B * (int64_t)m->tables_of_rank[j].size() * D);
+        if ((rc = dalloc(m, &m->a2a_send, (size_t)(m->Bg * m->Tl * D)))) return fail(rc);
+        if ((rc = dalloc(m, &m->a2a_recv, (size_t)((int64_t)m->B * m->n_tw * D)))) return fail(rc);
+        if ((rc = dalloc(m, &m->g_send, (size_t)((int64_t)m->B * m->n_tw * D)))) return fail(rc);
+        if ((rc = dalloc(m, &m->g_recv, (size_t)(m->Bg * m->Tl * D)))) return fail(rc);
+        if (m->Trw) {
+            if ((rc = dalloc(m, &m->rw_part, (size_t)(m->Bg * m->Trw * D)))) return fail(rc);
+            if ((rc = dalloc(m, &m->rw_local, (size_t)((int64_t)m->B * m->Trw * D)))) return fail(rc);
+        }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "model initialisation failed"));
+    *out = m;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_info(const dlrm_model *m, dlrm_model_info_t *info) {
+    DLRM_REQUIRE(m != nullptr && info != nullptr, "NULL argument");
+    info->d_params = m->params; info->d_grads = m->grads; info->n_params = m->n_params;
+    info->d_weight = m->weight; info->total_rows = m->total_rows; info->d_opt_state = m->opt_state;
+    info->num_local_tables = m->Tl + m->Trw; info->num_whole_tables = m->Tl;
+    info->d_pred = m->pred; info->d_loss = m->loss; info->d_error_flag = m->err_flag;
+    info->d_dense = m->x_dense; info->dense_ld = m->x_ld; info->d_labels = m->labels;
+    info->n_bottom = (int32_t)m->bot.size(); info->n_top = (int32_t)m->topl.size();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_local_table(const dlrm_model *m, int32_t local_table, int32_t *global_table, int64_t *first_pool_row,
+                                      int64_t *rows, int64_t *first_table_row) {
+    DLRM_REQUIRE(m != nullptr && local_table >= 0 && local_table < m->Tl + m->Trw, "local table out of range");
+    if (global_table) *global_table = local_table < m->Tl ? m->my_tables[local_table] : m->rw_tables[local_table - m->Tl];
+    if (first_pool_row) *first_pool_row = m->tro[local_table];
+    if (rows) *rows = m->local_rows[local_table];
+    if (first_table_row) *first_table_row = m->shard_begin_h[local_table];
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_feature_order(const dlrm_model *m, int32_t *order) {
+    DLRM_REQUIRE(m != nullptr && order != nullptr, "NULL argument");
+    for (int i = 0; i < m->T; i++) order[i] = m->feature_order[i];
+    return DLRM_OK;
+}
+
+static const Layer *find_layer(const dlrm_model *m, int32_t stack, int32_t layer) {
+    const std::vector<Layer> &st = stack == 0 ? m->bot : m->topl;
+    if (stack < 0 || stack > 1 || layer < 0 || layer >= (int)st.size()) return nullptr;
+    return &st[layer];
+}
+
+extern "C" int dlrm_model_layer(const dlrm_model *m, int32_t stack, int32_t layer, int32_t *N, int32_t *K, int64_t *w_offset,
+                                int64_t *w_ld, int64_t *b_offset) {
+    DLRM_REQUIRE(m != nullptr, "model is NULL");
+    const Layer *l = find_layer(m, stack, layer);
+    DLRM_REQUIRE(l != nullptr, "no layer %d in stack %d", layer, stack);
+    if (N) *N = l->N;
+    if (K) *K = l->K;
+    if (w_offset) *w_offset = l->w_off;
+    if (w_ld) *w_ld = l->w_ld;
+    if (b_offset) *b_offset = l->b_off;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_set_layer(dlrm_model *m, int32_t stack, int32_t layer, const float *h_w, const float *h_b) {
+    DLRM_REQUIRE(m != nullptr && h_w != nullptr && h_b != nullptr, "NULL argument");
+    const Layer *l = find_layer(m, stack, layer);
+    DLRM_REQUIRE(l != nullptr, "no layer %d in stack %d", layer, stack);
+    DLRM_HIP(hipMemcpy2D(m->params + l->w_off, sizeof(float) * l->w_ld, h_w, sizeof(float) * l->K, sizeof(float) * l->K, l->N,
+                         hipMemcpyHostToDevice));
+    DLRM_HIP(hipMemcpy(m->params + l->b_off, h_b, sizeof(float) * l->N, hipMemcpyHostToDevice));
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_get_layer(const dlrm_model *m, int32_t stack, int32_t layer, float *h_w, float *h_b) {
+    DLRM_REQUIRE(m != nullptr && h_w != nullptr && h_b != nullptr, "NULL argument");
+    const Layer *l = find_layer(m, stack, layer);
+    DLRM_REQUIRE(l != nullptr, "no layer %d in stack %d", layer, stack);
+    DLRM_HIP(hipDeviceSynchronize());
+    DLRM_HIP(hipMemcpy2D(h_w, sizeof(float) * l->K, m->params + l->w_off, sizeof(float) * l->w_ld, sizeof(float) * l->K, l->N,
+                         hipMemcpyDeviceToHost));
+    DLRM_HIP(hipMemcpy(h_b, m->params + l->b_off, sizeof(float) * l->N, hipMemcpyDeviceToHost));
+    return DLRM_OK;
+}
+
+// Xavier-style normal init of every layer from one seed (the same on every rank: replicas start identical);
+// the reference binds unscaled randn weights (src/dlrmtest.cpp:110-113)
+extern "C" int dlrm_model_init_dense(dlrm_model *m, uint64_t seed) {
+    DLRM_REQUIRE(m != nullptr, "model is NULL");
+    uint64_t s = splitmix64(seed ^ 0x6d6c705f696e6974ull);
+    auto uni = [&]() { s = splitmix64(s); return (float)(s >> 40) * (1.0f / 16777216.0f); };
+    auto nrm = [&]() { const float u1 = uni() + 1e-7f, u2 = uni(); return std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2); };
+    for (int stack = 0; stack < 2; stack++) {
+        const std::vector<Layer> &st = stack == 0 ? m->bot : m->topl;
+        for (size_t i = 0; i < st.size(); i++) {
+            const Layer &l = st[i];
+            std::vector<float> w((size_t)l.N * l.K), b(l.N);
+            const float sw = std::sqrt(2.0f / (float)(l.K + l.N)), sb = std::sqrt(1.0f / (float)l.N);
+            for (auto &x : w) x = nrm() * sw;
+            for (auto &x : b) x = nrm() * sb;
+            if (int rc = dlrm_model_set_layer(m, stack, (int)i, w.data(), b.data())) return rc;
+        }
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_load_batch(dlrm_model *m, const float *d_dense, int64_t dense_ld, const float *d_labels,
+                                     dlrm_stream_t stream) {
+    DLRM_REQUIRE(m != nullptr && d_dense != nullptr && d_labels != nullptr, "NULL argument");
+    DLRM_REQUIRE(dense_ld >= m->cfg.dense_in, "dense_ld too small");
+    hipStream_t s = as_stream(stream);
+    if (int rc = dlrm_copy_2d(m->x_dense, m->x_ld, d_dense, dense_ld, m->B, m->cfg.dense_in, s)) return rc;
+    DLRM_HIP(hipMemcpyAsync(m->labels, d_labels, sizeof(float) * m->B, hipMemcpyDeviceToDevice, s));
+    return DLRM_OK;
+}
+
+static int ensure_sparse_ws(dlrm_model *m, const void *idx, const void *off, int64_t n_idx) {
+    for (int rw = 0; rw < 2; rw++) {
+        if (rw ? !(m->Trw && m->sharded) : !m->Tl) continue;
+        dlrm_embbag e = table_desc(m, rw != 0, idx, off, n_idx);
+        size_t need = 0;
+        if (int rc = dlrm_embbag_backward_workspace_bytes(&e, &need)) return rc;
+        size_t &have = rw ? m->ws_sparse_rw_bytes : m->ws_sparse_bytes;
+        void *&ws = rw ? m->ws_sparse_rw : m->ws_sparse;
+        if (need > have) {
+            // grows with the first batch of a new size only (a steady loop never allocates)
+            DLRM_HIP(hipDeviceSynchronize());
+            char *p = nullptr;
+            if (int rc = dalloc(m, &p, need, false)) return rc;
+            ws = p; have = need;
+        }
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_forward(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices,
+                                  dlrm_stream_t stream) {
+    DLRM_REQUIRE(m != nullptr, "model is NULL");
+    DLRM_REQUIRE((d_indices != nullptr || n_indices == 0) && d_offsets != nullptr && n_indices >= 0, "bad batch");
+    return forward_pass(m, d_indices, d_offsets, n_indices, false, as_stream(stream));
+}
+
+extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices,
+                                     dlrm_stream_t stream) {
+    DLRM_REQUIRE(m != nullptr, "model is NULL");
+    DLRM_REQUIRE((d_indices != nullptr || n_indices == 0) && d_offsets != nullptr && n_indices >= 0, "bad batch");
+    hipStream_t main = as_stream(stream);
+    hipStream_t emb = m->s_emb ? m->s_emb : main;
+    const dlrm_model_config &c = m->cfg;
+    if (int rc = ensure_sparse_ws(m, d_indices, d_offsets, n_indices)) return rc;
+    if (int rc = forward_pass(m, d_indices, d_offsets, n_indices, true, main)) return rc;
+    // loss (means over the GLOBAL batch, so the ranks' gradients add)
+    if (c.loss == DLRM_LOSS_BCE) {
+        if (int rc = dlrm_loss_bce_logits(m->pred, m->labels, m->B, m->Bg, m->loss, m->dpred, main)) return rc;
+    } else {
+        if (int rc = dlrm_loss_mse(m->pred, m->labels, m->B, m->Bg, m->loss, m->dpred, c.final_relu, main)) return rc;
+    }
+    // top MLP backward, interaction backward
+    if (m->dot) {
+        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, m->dinter, m->inter_ld, main))
+            return rc;
+        if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_BACKWARD, main, [&] {
+                return dlrm_interact_dot_backward(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, main);
+            }))
+            return rc;
+    } else {
+        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, nullptr, 0, main)) return rc;
+        // the bottom part of the concatenation is a ReLU output, the pooled part is not
+        const int nb = m->bottom.back();
+        const float *dz0 = m->topl.size() > 1 ? m->top_dz[0].p : m->dpred;
+        const int64_t dz0_ld = m->topl.size() > 1 ? m->top_dz[0].ld : 1;
+        if (int rc = linear_dgrad(m, m->topl[0], 0, nb, dz0, dz0_ld, m->dfeat, m->feat_ld, m->feat, m->feat_ld, main)) return rc;
+        if (int rc = linear_dgrad(m, m->topl[0], nb, m->top_in - nb, dz0, dz0_ld, m->dfeat + nb, m->feat_ld, nullptr, 0, main)) return rc;
+    }
+    // sparse rows (exchange + fused update) on the embedding stream beside the bottom MLP's backward
+    if (int rc = wait_for(m, emb, main)) return rc;     // dfeat is complete
+    if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, emb)) return rc;
+    if (int rc = stack_backward(m, m->bot, m->x_dense, m->x_ld, m->bot_acts, m->dfeat, m->feat_ld, m->bot_dz, nullptr, 0, main)) return rc;
+    if (m->s_wgrad)
+        if (int rc = wait_for(m, main, m->s_wgrad)) return rc;   // every dense gradient is there
+    if (m->sharded)
+        if (int rc = dlrm_comm_all_reduce_sum(c.comm, m->grads, m->n_params, main)) return rc;
+    if (int rc = wait_for(m, main, emb)) return rc;      // rows are updated before anyone reuses dfeat
+    return dlrm_sgd_step(m->params, m->grads, m->n_params, c.lr, main);
+}
+
+extern "C" int dlrm_model_enable_timing(dlrm_model *m, uint32_t class_mask, int32_t max_records) {
+    DLRM_REQUIRE(m != nullptr && max_records >= 0, "bad argument");
+    DLRM_HIP(hipDeviceSynchronize());
+    m->time_mask = class_mask;
+    m->n_trecs = 0;
+    while ((int32_t)m->trecs.size() < max_records) {
+        dlrm_model::TimeRec r{};
+        DLRM_HIP(hipEventCreate(&r.e0));
+        DLRM_HIP(hipEventCreate(&r.e1));
+        m->trecs.push_back(r);
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_model_collect_timing(dlrm_model *m, double *h_ms_sum, int64_t *h_launches) {
+    DLRM_REQUIRE(m != nullptr && h_ms_sum != nullptr && h_launches != nullptr, "NULL argument");
+    DLRM_HIP(hipDeviceSynchronize());
+    for (int c = 0; c < DLRM_TIME_NUM_CLASSES; c++) { h_ms_sum[c] = 0.0; h_launches[c] = 0; }
+    for (size_t i = 0; i < m->n_trecs; i++) {
+        float ms = 0.f;
+        DLRM_HIP(hipEventElapsedTime(&ms, m->trecs[i].e0, m->trecs[i].e1));
+        h_ms_sum[m->trecs[i].cls] += ms;
+        h_launches[m->trecs[i].cls] += 1;
+    }
+    m->n_trecs = 0;
+    return DLRM_OK;
+}

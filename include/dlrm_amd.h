@@ -9,7 +9,7 @@
  *
  * Sections: tables - EmbeddingBag (forward, fused sparse update) - MLP layers - interaction and losses -
  * page-LRU cache (dlrm_cache: declarations, then its calls further down) - Criteo record decode - recorded
- * step (dlrm_plan) - vector-granular cache (dlrm_vcache) - collectives (dlrm_comm).
+ * step (dlrm_plan) - vector-granular cache (dlrm_vcache) - collectives (dlrm_comm) - whole model (dlrm_model).
  *
  * Conventions
  *  - Every function returns DLRM_OK (0) or an error code; the message of the
@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1009
+#define DLRM_ABI_VERSION 1010
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -64,7 +64,8 @@ const char *dlrm_target_arch(void);
 
 /*
  * Fill n elements (first .. first+n of a table's flat element stream) with
- * uniform [0,1): value(i) = (splitmix64(seed + i) >> 40) * 2^-24.
+ * uniform [0,1): value(i) = (splitmix64(splitmix64(seed) + i) >> 40) * 2^-24 (the seed is hashed, so the
+ * streams of nearby seeds -- one per table -- are unrelated).
  * Replaces embedding_table_init::write() -> DATA::initial()
  * (include/data.h:217, src/data_transfer.cpp:47-61: rand()/(RAND_MAX+1.0)).
  * dst may be device memory or host-mapped pinned memory.
@@ -620,6 +621,116 @@ int dlrm_comm_reduce_scatter_sum(dlrm_comm *c, const float *d_send, float *d_rec
                                  dlrm_stream_t stream);
 /* d_recv[p * send_count + i] = rank p's d_send[i]. */
 int dlrm_comm_all_gather(dlrm_comm *c, const float *d_send, float *d_recv, int64_t send_count, dlrm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * The whole model behind one handle: what a C or C++ host needs to run the train / inference step of the
+ * Criteo-shaped models without assembling it from the operators above.  Stands for the loop body of the
+ * reference's main() (src/dlrmtest.cpp:473-545: build emb, forward, loss, backward, optimizer step,
+ * update_parameter) with struct emb (:144-210) and struct Net2 (:217-278) inside.  One handle per process and
+ * GPU; with world > 1 (or force_exchange) the tables are sharded over the ranks of `comm` -- whole tables by
+ * table_owner[t] = rank (pooled vectors travel with an all-to-all), tables with owner -1 split into one
+ * contiguous row range per rank (reduce-scatter / all-gather) -- and the MLPs are data parallel (all-reduce
+ * of the flat gradient buffer).  Every rank passes the ids of ITS tables (dlrm_model_local_table order: whole
+ * tables ascending, then the row-wise ones) for the GLOBAL batch, table-major with include_last_offset
+ * offsets, as dlrm_ids_regroup produces them.  The step's kernels run on the caller's stream and up to three
+ * streams of the model; on return everything the step depends on is ordered behind the caller's stream.
+ * ------------------------------------------------------------------------ */
+typedef struct dlrm_model dlrm_model;
+enum { DLRM_INTERACT_DOT = 0, DLRM_INTERACT_CAT = 1 };   /* cat: torch::cat of src/dlrmtest.cpp:265 */
+enum { DLRM_LOSS_BCE = 0, DLRM_LOSS_MSE = 1 };           /* mse: torch::mse_loss of :522 */
+
+typedef struct dlrm_model_config {
+    int32_t num_tables;
+    const int64_t *table_rows;   /* host int64[T] */
+    int32_t dim;
+    int32_t dense_in;
+    int32_t n_bottom;
+    const int32_t *bottom;       /* host: widths of the bottom MLP's layers (all ReLU); dot needs the last == dim */
+    int32_t n_top;
+    const int32_t *top;          /* host: widths of the top MLP's layers, the last one 1 */
+    int32_t interaction;         /* DLRM_INTERACT_* */
+    int32_t loss;                /* DLRM_LOSS_* */
+    int32_t final_relu;          /* ReLU on the last layer too, as the reference has it (:270) */
+    int32_t pooling;             /* DLRM_POOL_* */
+    int32_t row_dtype;           /* DLRM_F32 | DLRM_BF16 */
+    int32_t idx_dtype;           /* DLRM_I32 | DLRM_I64 */
+    int32_t emb_optimizer;       /* DLRM_OPT_* */
+    int32_t gemm_mode;           /* DLRM_GEMM_* */
+    float lr, eps;
+    int64_t local_batch;         /* samples whose MLP runs on this rank */
+    int32_t rank, world;
+    dlrm_comm *comm;             /* required when world > 1 or force_exchange */
+    const int32_t *table_owner;  /* host int32[T]: owning rank, -1 = split by rows; NULL = whole tables placed */
+                                 /* greedily (biggest first, to the rank with the fewest tables, then bytes) */
+    int32_t force_exchange;      /* run the sharded schedule (every exchange, with one peer) even when world == 1 */
+    int32_t overlap;             /* embedding side on its own stream: 1 / 0, -1 = when sharded */
+    int32_t presort;             /* sort the sparse update's occurrences beside the forward pass (own stream) */
+    int32_t wgrad_stream;        /* weight gradients on their own stream: 1 / 0, -1 = when local_batch <= 32768 */
+    uint64_t seed;               /* tables: uniform [0,1), table t seeded (seed << 20) + 7919 (t + 1) */
+    int32_t init_tables;         /* 0 = leave the table memory as allocated (the caller fills it) */
+} dlrm_model_config;
+
+typedef struct dlrm_model_info_t {
+    float *d_params, *d_grads;   /* flat dense parameters / gradients: see dlrm_model_layer */
+    int64_t n_params;
+    void *d_weight;              /* [total_rows, dim]: this rank's tables back to back */
+    int64_t total_rows;
+    float *d_opt_state;          /* Adagrad: float[total_rows], else NULL */
+    int32_t num_local_tables, num_whole_tables;
+    float *d_pred;               /* [local_batch] predictions (logits for DLRM_LOSS_BCE) of the last step */
+    float *d_loss;               /* this rank's share of the global-mean loss of the last train step */
+    int32_t *d_error_flag;       /* raised by the EmbeddingBag kernels on an out-of-range id */
+    float *d_dense;              /* [local_batch, dense_ld] input buffer (dlrm_model_load_batch fills it) */
+    int64_t dense_ld;
+    float *d_labels;             /* [local_batch] */
+    int32_t n_bottom, n_top;
+} dlrm_model_info_t;
+
+int dlrm_model_create(const dlrm_model_config *cfg, dlrm_model **out);
+int dlrm_model_destroy(dlrm_model *m);
+int dlrm_model_info(const dlrm_model *m, dlrm_model_info_t *info);
+/* local table i (0 .. num_local_tables): its global table id, first row inside d_weight, rows held, and the
+ * table row its first held row is (0 for whole tables).  Any output may be NULL. */
+int dlrm_model_local_table(const dlrm_model *m, int32_t local_table, int32_t *global_table, int64_t *first_pool_row,
+                           int64_t *rows, int64_t *first_table_row);
+/* order[f] = table whose pooled vector is feature f + 1 of the interaction (whole tables rank-major, then the
+ * row-wise ones): the table order of the top MLP's first-layer columns, and what dlrm_criteo_decode's
+ * d_table_order wants for the index exchange.  host int32[T]. */
+int dlrm_model_feature_order(const dlrm_model *m, int32_t *order);
+/* stack 0 = bottom, 1 = top.  Layer `layer`: W [N, K] at d_params + w_offset with row stride w_ld, bias [N] at
+ * d_params + b_offset (gradients at the same offsets of d_grads). */
+int dlrm_model_layer(const dlrm_model *m, int32_t stack, int32_t layer, int32_t *N, int32_t *K, int64_t *w_offset,
+                     int64_t *w_ld, int64_t *b_offset);
+int dlrm_model_set_layer(dlrm_model *m, int32_t stack, int32_t layer, const float *h_w /* [N,K] */, const float *h_b);
+int dlrm_model_get_layer(const dlrm_model *m, int32_t stack, int32_t layer, float *h_w, float *h_b);   /* synchronises */
+/* Normal(0, 2/(K+N)) weights and Normal(0, 1/N) biases from one seed (give every rank the same seed); the
+ * reference binds unscaled randn weights (src/dlrmtest.cpp:110-113). */
+int dlrm_model_init_dense(dlrm_model *m, uint64_t seed);
+/* copies a batch's dense features [local_batch, dense_in] (row stride dense_ld) and labels into the model */
+int dlrm_model_load_batch(dlrm_model *m, const float *d_dense, int64_t dense_ld, const float *d_labels, dlrm_stream_t stream);
+/* Net2::forward around emb::forward (src/dlrmtest.cpp:254-272, :170-206): predictions into d_pred */
+int dlrm_model_forward(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices, dlrm_stream_t stream);
+/* one iteration of the loop body (src/dlrmtest.cpp:505-535): forward, loss, backward, SGD on every dense
+ * parameter, fused sparse update of the rows.  The first step of a new batch size may allocate its sort
+ * workspace; later steps allocate nothing. */
+int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices,
+                          dlrm_stream_t stream);
+
+/*
+ * Optional timing of the step's operators, for benchmarks: every launch of a class whose bit is set in
+ * class_mask is bracketed by two events on the stream it runs on (at most max_records launches between two
+ * collects; further ones run untimed).  dlrm_model_collect_timing synchronises and returns milliseconds and
+ * launch counts summed per class (arrays of DLRM_TIME_NUM_CLASSES), then starts over.  The "_SKINNY" classes
+ * are the layers that are no matrix product (at most 16 inputs, or one output).  class_mask 0 switches it off.
+ */
+enum {
+    DLRM_TIME_LINEAR_FORWARD = 0, DLRM_TIME_LINEAR_BACKWARD_DATA, DLRM_TIME_LINEAR_BACKWARD_WEIGHT,
+    DLRM_TIME_LINEAR_FORWARD_SKINNY, DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY, DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY,
+    DLRM_TIME_EMBBAG_FORWARD, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, DLRM_TIME_EMBBAG_BACKWARD_UPDATE,
+    DLRM_TIME_INTERACT_DOT_FORWARD, DLRM_TIME_INTERACT_DOT_BACKWARD, DLRM_TIME_NUM_CLASSES
+};
+int dlrm_model_enable_timing(dlrm_model *m, uint32_t class_mask, int32_t max_records);
+int dlrm_model_collect_timing(dlrm_model *m, double *h_ms_sum, int64_t *h_launches);
 
 #ifdef __cplusplus
 }

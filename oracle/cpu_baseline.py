@@ -69,9 +69,7 @@ def cpu_train_step(cfg, tables, bottom, top, dense, idx_list, off, labels, lr):
     return float(loss.detach())
 
 
-def time_cpu_baseline(cfg, batch, table_rows_cap=200000, warmup=1, steps=3, seed=0):
-    """Returns dict(value=samples/s, cores, sample description)."""
-    rows, tables, bottom, top = build_cpu_model(cfg, table_rows_cap, seed)
+def _time_steps(cfg, tables, bottom, top, rows, batch, warmup, steps, seed):
     g = torch.Generator().manual_seed(seed + 1)
     dense = torch.randn(batch, cfg.dense_in, generator=g)
     labels = (torch.rand(batch, generator=g) < 0.25).float() if cfg.loss == "bce" else torch.randn(batch, generator=g)
@@ -86,12 +84,33 @@ def time_cpu_baseline(cfg, batch, table_rows_cap=200000, warmup=1, steps=3, seed
         if i >= warmup:
             times.append(dt)
     times.sort()
-    med = times[len(times) // 2]
+    return times[len(times) // 2]
+
+
+def time_cpu_baseline(cfg, batch=65536, table_rows_cap=2_000_000, warmup=2, steps=5, one_thread_batch=8192, seed=0):
+    """Median step time of `steps` train steps after `warmup` on every host thread ATen is given, at the
+    workload's own batch, plus a one-thread run on a smaller batch (samples/s scale with neither).  Tables are
+    capped at table_rows_cap rows: building 96 GB of tables on the host would take longer than the whole
+    benchmark; the cap is reported.  Returns the cpu_baseline object of the bench line."""
+    rows, tables, bottom, top = build_cpu_model(cfg, table_rows_cap, seed)
+    threads = torch.get_num_threads()
+    med = _time_steps(cfg, tables, bottom, top, rows, batch, warmup, steps, seed)
+    torch.set_num_threads(1)
+    try:
+        b1 = min(one_thread_batch, batch)
+        med1 = _time_steps(cfg, tables, bottom, top, rows, b1, 1, 3, seed)
+    finally:
+        torch.set_num_threads(threads)
     return {
         "value": batch / med,
         "unit": "samples/s",
-        "cores": torch.get_num_threads(),
+        "cores": threads,
         "kind": "port",
-        "sample": "%d train steps of batch %d, same model shape, tables capped at %d rows (host memory), "
-                  "libtorch CPU kernels via ATen, median step %.3f s" % (steps, batch, table_rows_cap, med),
+        "table_rows_cap": table_rows_cap,
+        "table_GB": sum(rows) * cfg.dim * 4 / 1e9,
+        "one_thread": {"value": b1 / med1, "unit": "samples/s", "cores": 1, "batch": b1, "median_step_s": med1},
+        "sample": "%d train steps (after %d warm-ups) of batch %d, same model shape, tables capped at %d rows "
+                  "(%.1f GB on the host), libtorch CPU kernels via ATen on %d threads, median step %.3f s; "
+                  "one thread: 3 steps of batch %d, median %.3f s"
+                  % (steps, warmup, batch, table_rows_cap, sum(rows) * cfg.dim * 4 / 1e9, threads, med, b1, med1),
     }

@@ -77,8 +77,9 @@ static inline uint64_t splitmix64(uint64_t x) {
 }
 
 void orc_table_init_uniform(float *w, int64_t n, uint64_t seed, int64_t first) {
+    const uint64_t base = splitmix64(seed);
     for (int64_t i = 0; i < n; i++)
-        w[i] = (float)(splitmix64(seed + (uint64_t)(first + i)) >> 40) * (1.0f / 16777216.0f);
+        w[i] = (float)(splitmix64(base + (uint64_t)(first + i)) >> 40) * (1.0f / 16777216.0f);
 }
 
 /* -------------------------------------------------- EmbeddingBag forward -- */

@@ -193,3 +193,22 @@ def test_driver_vector_policy_small(oracle, tmp_path):
             ref.append((reads.tolist(), writes.tolist()))
     assert parse_csv(tmp_path / "v.csv", T) == ref
     assert sum(sum(w) for _, w in ref) > 0
+
+
+def test_cpp_train_host_single_and_forced_exchange():
+    """adapter/bin/dlrm_train: the Criteo-shaped step hosted in C++ over dlrm_model_* (no Python in the process).
+    One rank without exchanges, the same with every exchange of the sharded schedule over a dlrm_comm (RCCL)
+    communicator of one rank, and with the large tables split by rows: same batches, same seeds, so the loss after
+    the last step of the first two must agree to float32 rounding."""
+    exe = os.path.join(ROOT, "adapter", "bin", "dlrm_train")
+    base = [exe, "--config", "kaggle", "--row-cap", "20000", "--batch", "1024", "--steps", "6", "--warmup", "2"]
+    losses = []
+    for extra in ([], ["--force-exchange"], ["--force-exchange", "--row-wise-min-rows", "20000"]):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stderr
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert rec["samples_per_s"] > 0 and np.isfinite(rec["loss_share"]) and 0.0 < rec["loss_share"] < 5.0
+        assert rec["exchange"] == bool(extra)
+        losses.append(rec["loss_share"])
+    # (with row-wise tables the interaction sees the features in another order: another model from the same seed)
+    assert abs(losses[0] - losses[1]) <= 2e-5 * abs(losses[0]), losses

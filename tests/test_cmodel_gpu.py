@@ -1,0 +1,90 @@
+"""The whole-model handle of the C ABI (dlrm_model_*: placement, streams, exchanges and operator order inside
+libdlrm_amd.so, no Python in the step) against the same step assembled from the CPU oracle -- the comparison of
+tests/test_model_gpu.py, driven through the entry points a C++ host calls.  Single GPU, and the sharded schedule
+over a dlrm_comm (RCCL) communicator of one rank with whole and row-wise split tables.
+Tolerance: 1e-5 relative to each tensor's largest |reference| value; loss 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_model import make_batch, oracle_train_step
+from tests.test_embbag_forward_gpu import rel_err
+from tests.test_model_gpu import small_cfgs
+
+pytestmark = pytest.mark.gpu
+
+
+def tables_of(m):
+    out = {}
+    for g, first, rows, lo in m.local_tables:
+        out[g] = (m.weight[first:first + rows].float().cpu().numpy().copy(), lo)
+    return out
+
+
+def local_batch_ids(m, cfg, idx, off, B):
+    """the ids of the model's local tables, in its order, out of a batch in global table order"""
+    segs, lens = [], []
+    for g, _, _, _ in m.local_tables:
+        s, e = off[g * B], off[(g + 1) * B]
+        segs.append(idx[s:e])
+        lens.append(np.diff(off[g * B:(g + 1) * B + 1]))
+    li = np.concatenate(segs) if segs else np.zeros(0, np.int64)
+    lo = np.concatenate([[0], np.cumsum(np.concatenate(lens))]) if lens else np.zeros(1, np.int64)
+    return li, lo
+
+
+@pytest.mark.parametrize("name", ["mlperf_like", "kaggle_like", "rmc1_like", "adagrad_bf16rows_off"])
+@pytest.mark.parametrize("mode", ["single", "exchange", "exchange-rw"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged):
+    from dlrm_amd import comm
+    from dlrm_amd.cmodel import CModel
+    cfg = small_cfgs()[name]
+    B, T = 37, cfg.num_tables
+    cm, owner = None, None
+    if mode != "single":
+        cm = comm.Comm(comm.unique_id(), 0, 1)
+        if mode == "exchange-rw":      # the two largest tables are split by rows (one range: the only rank's)
+            big = sorted(range(T), key=lambda t: -cfg.table_rows[t])[:2]
+            owner = [-1 if t in big else 0 for t in range(T)]
+    m = CModel(cfg, B, comm=cm, table_owner=owner, seed=3, force_exchange=mode != "single", idx_dtype=torch.int64)
+    m.init_dense(7)
+    Ws, bs = m.get_dense()
+    if name == "rmc1_like":            # positive biases keep the all-ReLU reference model alive
+        bs = [np.abs(b) for b in bs]
+        m.set_dense(Ws, bs)
+    got = tables_of(m)
+    tables = [got[t][0] for t in range(T)]
+    state = None if m.opt_state is None else np.zeros(sum(cfg.table_rows), np.float32)
+    n_bottom = len(cfg.bottom)
+    rng = np.random.default_rng(17)
+    for step in range(3):
+        dense, idx, off, labels = make_batch(rng, cfg, B, ragged)
+        li, lo = local_batch_ids(m, cfg, idx, off, B)
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        loss = m.train_step(torch.from_numpy(li).cuda(), torch.from_numpy(lo).cuda())
+        torch.cuda.synchronize()
+        assert int(m.err_flag.item()) == 0
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, n_bottom, cfg.lr,
+                                               feature_order=m.feature_order, emb_opt_state=state)
+        assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        for t, (a, _) in tables_of(m).items():
+            assert rel_err(a, tables[t]) <= 1e-5, t
+        gW, gb = m.get_dense()
+        for a, r in zip(gW + gb, Ws + bs):
+            assert rel_err(a, r) <= 1e-5
+    # inference changes nothing and predicts what the oracle's forward pass predicts
+    import copy
+    dense, idx, off, labels = make_batch(rng, cfg, B, ragged)
+    li, lo = local_batch_ids(m, cfg, idx, off, B)
+    m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+    pred = m.forward(torch.from_numpy(li).cuda(), torch.from_numpy(lo).cuda())
+    torch.cuda.synchronize()
+    _, pred_ref = oracle_train_step(oracle, cfg, copy.deepcopy(tables), copy.deepcopy(Ws), copy.deepcopy(bs), dense, idx,
+                                    off, labels, n_bottom, cfg.lr, feature_order=m.feature_order,
+                                    emb_opt_state=None if state is None else state.copy())
+    assert rel_err(pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+    m.close()
+    if cm is not None:
+        cm.close()
