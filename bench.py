@@ -242,12 +242,14 @@ def roofline_of(dom, gemm_mode, traffic):
     return r
 
 
-def load_traffic(world):
-    """HBM bytes per operator launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)."""
-    for name in ("round2_hbm_traffic.json", "round1_hbm_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if world == 1 and os.path.exists(tpath):
-            return json.load(open(tpath)).get("per_op_bytes_per_launch", {})
+def load_traffic(world, workload):
+    """HBM bytes per operator launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) of the
+    same workload ("config:global batch") on one GPU; nothing for any other run."""
+    tpath = os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        d = json.load(open(tpath))
+        if d.get("workload") == workload:
+            return d.get("per_op_bytes_per_launch", {})
     return {}
 
 
@@ -338,7 +340,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     loss_value = float(loss.item())
     timed_ids = [args.warmup + i for i in range(args.steps)]
     dom_rows = kernel_rows(model.collect_timing(), work_for(timed_ids), args.steps, gemm_name, gemm_peak)
-    traffic = load_traffic(world)
+    traffic = load_traffic(world, "%s:%d" % (args.config, Bg))
     roofline = roofline_of(dom_rows[0], gemm_mode, traffic) if dom_rows else None
     if roofline:
         roofline["timed"] = "HIP events around this operator's launches inside the timed steps"
@@ -626,9 +628,8 @@ def main():
                                      if gemm_mode == 1 else "float32 MFMA dense peak")
             roofline["mfma_tflops_executed"] = dom["achieved"] * (6.0 if gemm_mode == 1 else 1.0)
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
-        tpath = os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("per_op_bytes_per_launch", {})
+        traffic = {} if cached else load_traffic(world, "%s:%d" % (args.config, Bg))
+        if traffic:
             for k in kernels:
                 k["traffic"] = traffic.get(k["op"])
             roofline["traffic"] = traffic.get(dom["op"])

@@ -6,12 +6,15 @@
 //              primitive, only as many key bits as total_rows needs).  Stability
 //              keeps the occurrences of one row in position order, so the
 //              reduction order -- and the result -- is reproducible.
-//  3. update : one G-lane group per sorted position; the group that sits on
-//              the first occurrence of a row (its "leader") sums the pooled
-//              gradients of all occurrences of that row, applies SGD or
-//              row-wise Adagrad and writes the row back.  Every touched row is
-//              read once and written once; other groups exit after two key
-//              loads.
+//  3. update : segmented reduction over the sorted occurrences fused with the optimizer step
+//              (sparse_update_kernel).  A workgroup owns one or two stretches of kSegLen sorted
+//              positions, each G-lane group a few consecutive positions of it, fetched kChunk gradient
+//              rows (and the table rows of the runs ending there) at a time.  A run of equal keys inside
+//              one group is summed in position order and applied there (SGD or row-wise Adagrad); pieces
+//              of a run that crosses groups meet in LDS and the group where the run ends applies it;
+//              pieces of a run that crosses a stretch boundary go to the `partial` slabs of the workspace.
+//  4. combine: combine_runs_kernel adds the slabs of each run that crossed a stretch boundary, in
+//              position order, and applies the step.  Every touched row is read once and written once.
 //
 // HBM-bound: algorithmic bytes per call = n_idx*dim*4 (gradient rows) +
 // 2*U*dim*row_bytes (read-modify-write of U unique rows) + n_idx*idx_bytes.
@@ -493,17 +496,23 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
     }
 }
 
-// One group per kSegLen positions: if a run starts inside this stretch and goes on beyond it, sum
-// its pieces in position order and apply the update.
+// One workgroup per stretch of kSegLen positions: if a run starts inside this stretch and goes on beyond it, add up
+// its pieces and apply the update.  The run's later stretches are dealt round-robin, kU at a time, to the groups
+// of the workgroup (a 3-row table hit by a 65536-sample batch is a run of 170 stretches: one group walking them
+// alone is a chain of 22 dependent round trips to memory); every group adds its share in position order and
+// group 0 adds the groups' sums in group order, so the result does not depend on timing.
 template <typename KEY, typename ROW, int VEC16, int G, int NC>
 __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, const KEY *__restrict__ keys,
                                                                     const float *__restrict__ partial, int dpad) {
     using RW = RowRW<ROW, VEC16>;
     constexpr int NF = RW::NF;
     constexpr int GROUPS = kBwdThreads / G;
+    constexpr int DP = NC * G * NF;
+    __shared__ __attribute__((aligned(16))) float s_sum[GROUPS][DP];
     const int grp = threadIdx.x / G, lig = threadIdx.x % G;
-    const int64_t c0 = (int64_t)blockIdx.x * GROUPS + grp;
+    const int64_t c0 = blockIdx.x;
     const int64_t s0 = c0 * kSegLen;
+    // (every exit below depends on the stretch only: the whole workgroup takes it together)
     if (s0 >= p.n_idx) return;
     const int64_t e = min(p.n_idx, s0 + kSegLen) - 1;
     if (e + 1 >= p.n_idx) return;
@@ -525,11 +534,11 @@ __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, 
     for (int c = 0; c < NC; c++) {
 #pragma unroll
         for (int q = 0; q < NF; q++) acc[c][q] = 0.f;
-        if (col_ok[c]) load_vec<NF>(src + col[c], acc[c]);
+        if (grp == 0 && col_ok[c]) load_vec<NF>(src + col[c], acc[c]);
     }
     constexpr int kU = 8;
     const int64_t n_seg = (p.n_idx + kSegLen - 1) / kSegLen;
-    for (int64_t cc = c0 + 1; cc < n_seg && keys[cc * kSegLen] == k; cc += kU) {
+    for (int64_t cc = c0 + 1 + (int64_t)grp * kU; cc < n_seg && keys[cc * kSegLen] == k; cc += (int64_t)GROUPS * kU) {
         const float *pp[kU];
         float m[kU];
 #pragma unroll
@@ -551,6 +560,21 @@ __global__ __launch_bounds__(kBwdThreads) void combine_runs_kernel(BwdParams p, 
                     for (int q = 0; q < NF; q++) acc[c][q] += v[u][q] * m[u];
             }
     }
+    if (grp > 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) store_vec<NF>(&s_sum[grp][(c * G + lig) * NF], acc[c]);
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    for (int g = 1; g < GROUPS; g++) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float v[NF];
+            load_vec<NF>(&s_sum[g][(c * G + lig) * NF], v);
+#pragma unroll
+            for (int q = 0; q < NF; q++) acc[c][q] += v[q];
+        }
+    }
     apply_row_update<ROW, VEC16, G, NC>(p, (int64_t)k, acc, col, col_ok, lig);
 }
 
@@ -565,8 +589,8 @@ static int launch_update(const BwdParams &p, const KEY *keys, const int32_t *val
     DLRM_LAUNCH_CHECK();
     if (!p.last_wins && p.n_idx > kSegLen) {
         const int64_t segs = ceil_div(p.n_idx, kSegLen);
-        hipLaunchKernelGGL((combine_runs_kernel<KEY, ROW, VEC16, G, NC>), dim3((unsigned)ceil_div(segs, kBwdThreads / G)),
-                           dim3(kBwdThreads), 0, s, p, keys, partial, dpad);
+        hipLaunchKernelGGL((combine_runs_kernel<KEY, ROW, VEC16, G, NC>), dim3((unsigned)segs), dim3(kBwdThreads), 0, s, p,
+                           keys, partial, dpad);
         DLRM_LAUNCH_CHECK();
     }
     return DLRM_OK;

@@ -344,17 +344,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 // below 2^-26 |ab|, so the result carries float32 accuracy (measured against a float64 reference it
 // is as close as the float32 MFMA path) at 6 x 32 cycles per 16-deep step instead of 8 x 64.
 //
-// Pipeline.  Global tiles are 128 x 32 float32 per operand, loaded into registers two half-steps
+// Pipeline.  Global tiles are R x 32 float32 per operand (R = the workgroup tile's extent on that
+// operand's output index, 128 or 64), loaded into registers two half-steps
 // before their first use.  LDS holds two stages of one 16-deep half-step each (three bf16 planes
-// per operand); while the 24 MFMAs of half-step j run out of stage j&1, the same wave splits the
+// per operand); while the MFMAs of half-step j (24 for a 128 x 128 tile) run out of stage j&1, the same wave splits the
 // next half-step's 16 elements per lane and writes them to the other stage, so the split's VALU
 // work and LDS writes sit in the shadow of the MFMAs and one barrier per half-step is enough.
-//   RC planes: [128][16] bf16, 32-byte rows whose two 16-byte chunks swap places in every other
+//   RC planes: [R][16] bf16, 32-byte rows whose two 16-byte chunks swap places in every other
 //              group of 8 rows (conflict-free ds_write_b64 of the pieces and ds_read_b128 fragments
 //              of 8 k-values)
-//   RS planes: [16][128] bf16, 256-byte rows with the 16-byte chunks XOR-swizzled; fragments come
+//   RS planes: [16][R] bf16, 2R-byte rows with the 16-byte chunks XOR-swizzled; fragments come
 //              out of the hardware transposing read ds_read_b64_tr_b16 (two per fragment)
-// 48 KB of LDS per workgroup; the register budget allows two workgroups per CU.
+// 48 KB of LDS per workgroup at 128 x 128 (12 KB per 64 of R and operand); the register budget allows two
+// workgroups per CU.
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -416,9 +418,13 @@ __device__ inline TileAddr<RC, R> make_tile_addr(const float *base, int64_t ld, 
         }
     } else {
         t.origin = base + o0;
+        // a piece that would start beyond the row's leading dimension re-reads the row's last piece: like the columns
+        // between o_end and ld it only feeds outputs that are never stored
+        int col = o0 + (tid % LPR) * 4;
+        if (col + 4 > (int)ld) col = (int)ld - 4;
 #pragma unroll
         for (int v = 0; v < R / 64; v++)
-            t.off[v] = (unsigned)((tid / LPR + (256 / LPR) * v) * (int)ld + (tid % LPR) * 4) * 4u;
+            t.off[v] = (unsigned)((tid / LPR + (256 / LPR) * v) * (int)ld + (col - o0)) * 4u;
     }
     return t;
 }
@@ -532,16 +538,33 @@ struct Frags {
     bf16x8 a[MI][3], b[NI][3];
 };
 
+// piece of A and piece of B that meet in cross term t, in the order mfma_frags issues the terms
+constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0};
+constexpr int kTermB[6] = {0, 1, 2, 0, 1, 0};
+
+// The reads are issued in the order the MFMAs first need them: the first MFMA waits for two fragments, not for
+// all of them (LDS reads return in order, so the wait before a use covers every read issued ahead of it).
 template <bool A_RC, bool B_RC, int TM, int TN>
 __device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags<TM / 64, TN / 64> &f) {
+    constexpr int MI = TM / 64, NI = TN / 64;
     const unsigned char *pa = stage, *pb = stage + 3 * plane_bytes(TM);
+    bool have_a[MI][3] = {}, have_b[NI][3] = {};
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) {
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int i = 0; i < TM / 64; i++) f.a[i][pl] = load_frag16<A_RC, TM>(pa + pl * plane_bytes(TM), wr * (TM / 2) + i * 32);
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-        for (int i = 0; i < TN / 64; i++) f.b[i][pl] = load_frag16<B_RC, TN>(pb + pl * plane_bytes(TN), wc * (TN / 2) + i * 32);
-    }
+            for (int t = 0; t < 6; t++) {
+                const int x = kTermA[t], y = kTermB[t];
+                if (!have_a[mi][x]) {
+                    f.a[mi][x] = load_frag16<A_RC, TM>(pa + x * plane_bytes(TM), wr * (TM / 2) + mi * 32);
+                    have_a[mi][x] = true;
+                }
+                if (!have_b[ni][y]) {
+                    f.b[ni][y] = load_frag16<B_RC, TN>(pb + y * plane_bytes(TN), wc * (TN / 2) + ni * 32);
+                    have_b[ni][y] = true;
+                }
+            }
 }
 
 // six cross terms for each of the wave's 32x32 accumulators, smallest terms first
@@ -552,12 +575,9 @@ __device__ inline void mfma_frags(const Frags<MI, NI> &f, f32x16 (&acc)[MI][NI])
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
             f32x16 c = acc[mi][ni];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][2], f.b[ni][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][1], f.b[ni][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][1], f.b[ni][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][0], f.b[ni][0], c, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][kTermA[t]], f.b[ni][kTermB[t]], c, 0, 0, 0);
             acc[mi][ni] = c;
         }
 }
@@ -612,8 +632,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
 
-    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || m0 + TM <= p.M || m0 + TM <= p.lda) &&
-                          (B_RC || n0 + TN <= p.N || n0 + TN <= p.ldb);
+    // (a_vec / b_vec: 16-byte aligned rows, so the leading dimensions are multiples of 4 elements; edge tiles of a
+    // reduction-strided operand read whole pieces up to the leading dimension, see make_tile_addr)
+    const bool vec_tile = p.a_vec && p.b_vec && (A_RC || p.lda >= 4) && (B_RC || p.ldb >= 4);
 
     // bias gradient (weight-gradient product only): this thread's four output rows of the A tile,
     // summed over every staged reduction row

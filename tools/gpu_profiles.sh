@@ -2,7 +2,7 @@
 # Collects the rocprofv3 summaries kept under profiles/: kernel traces (per-kernel average duration) and
 # FETCH_SIZE / WRITE_SIZE passes (HBM-side bytes) of the cache sweeps and of bench.py's other configurations.
 # Every profiled program runs under its own time limit; the script stops at the first failure.
-#   tools/gpu_profiles.sh <tag> [cache|kaggle|b8192|bench ...]
+#   tools/gpu_profiles.sh <tag> [cache|kaggle|b8192|bench|mfma ...]
 set -e
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -19,11 +19,12 @@ trace() {  # name, program args...
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- "$@" > "$OUT/$name.log" 2>&1
   python3 $ROOT/tools/prof_summary.py "$OUT/$name" "$OUT/$name" && rm -rf "$OUT/$name"
 }
-pmc() {    # name, counter, program args...
-  local name=$1 ctr=$2; shift 2
-  echo "== pmc $ctr: $name"
-  timeout -s KILL 240 rocprofv3 --pmc "$ctr" --output-format csv -d "$OUT/${name}_$ctr" -- "$@" > "$OUT/${name}_$ctr.log" 2>&1
-  python3 $ROOT/tools/prof_summary.py "$OUT/${name}_$ctr" "$OUT/${name}_$ctr" && rm -rf "$OUT/${name}_$ctr"
+pmc() {    # name, "counter [counter ...]" (one pass), program args...; files are tagged with the first counter
+  local name=$1 ctrs=$2; shift 2
+  local tag=${ctrs%% *}
+  echo "== pmc $ctrs: $name"
+  timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/${name}_$tag" -- "$@" > "$OUT/${name}_$tag.log" 2>&1
+  python3 $ROOT/tools/prof_summary.py "$OUT/${name}_$tag" "$OUT/${name}_$tag" && rm -rf "$OUT/${name}_$tag"
 }
 
 for w in $WHAT; do
@@ -50,6 +51,16 @@ for w in $WHAT; do
       trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline
       pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
       pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+      # (1 warm-up + 2 timed steps + the 2 operator-timing steps bench.py appends = 5 steps under the counters)
+      python3 $ROOT/tools/traffic_from_pmc.py "$OUT/bench_FETCH_SIZE_pmc.json" "$OUT/bench_WRITE_SIZE_pmc.json" 5 \
+        "$OUT/hbm_traffic.json" mlperf:65536
+      ;;
+    mfma)   # matrix-pipe busy cycles of the GEMM kernels in the step, at both batch sizes, and where their waves wait
+      M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
+      W="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+      pmc mfma_b65536 "$M" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+      pmc mfma_b8192 "$M" python3 $ROOT/bench.py --global-batch 8192 --steps 2 --warmup 1 --no-cpu-baseline
+      pmc wait_b65536 "$W" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
       ;;
   esac
 done

@@ -97,11 +97,15 @@ def embbag(rows=10_000_000, B=65536):
 
 
 def sparse(rows=10_000_000, B=65536):
+    """Fused sparse update, whole call (expand + sort + apply + combine): row width x row type x ids per bag x
+    id distribution x (sum|mean pooling) x (SGD | row-wise Adagrad).  Adagrad's bytes add the state row read and
+    written (one float per row for the row-wise form)."""
     out = []
     for D in (64, 128, 256):
         for dt in (torch.float32, torch.bfloat16):
             w = torch.empty(rows, D, device="cuda", dtype=dt)
             ops.table_init_uniform_(w, 1)
+            state = torch.zeros(rows, device="cuda")
             for L in (1, 8, 32, 128):
                 n = B * L
                 for dist in ("uniform", "zipf"):
@@ -113,18 +117,28 @@ def sparse(rows=10_000_000, B=65536):
                     U = int(torch.unique(idx).numel())
                     off = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
                     grad = torch.randn(B, D, device="cuda")
-                    ws = [None]
+                    for mode, opt in (("sum", "sgd"), ("mean", "sgd"), ("sum", "adagrad")):
+                        ws = [None]
+                        pool = _capi.POOL_MEAN if mode == "mean" else _capi.POOL_SUM
+                        kw = dict(optimizer=_capi.OPT_ADAGRAD_ROWWISE, opt_state=state) if opt == "adagrad" else {}
 
-                    def run():
-                        ws[0] = ops.embbag_backward_update(w, idx, off, B, grad, 1, None, _capi.POOL_SUM, True,
-                                                           lr=0.0, workspace=ws[0])
-                    t = timeit(run, iters=5, warmup=1)
-                    byt = B * D * 4 + 2 * U * D * w.element_size() + n * 4
-                    rec = {"op": "bwd_sgd", "D": D, "rows": "bf16" if dt == torch.bfloat16 else "f32", "L": L,
-                           "ids": dist, "unique": U, "us": t * 1e6, "GBps": byt / t / 1e9}
-                    out.append(rec)
-                    print(json.dumps(rec))
-            del w
+                        def run():
+                            ws[0] = ops.embbag_backward_update(w, idx, off, B, grad, 1, None, pool, True,
+                                                               lr=0.0, workspace=ws[0], **kw)
+                        t = timeit(run, iters=5, warmup=1)
+                        # the second half alone (what a train step has on its critical path once the sort of the
+                        # ids runs beside the forward pass on another stream)
+                        ws[0] = ops.embbag_backward_prepare(w, idx, off, B, 1, None, pool, True, workspace=ws[0])
+                        t_a = timeit(lambda: ops.embbag_backward_apply(w, idx, off, B, grad, ws[0], 1, None, pool, True,
+                                                                       lr=0.0, **kw), iters=5, warmup=1)
+                        byt = B * D * 4 + 2 * U * D * w.element_size() + n * 4 + (2 * U * 4 if opt == "adagrad" else 0)
+                        rec = {"op": "bwd", "opt": opt, "mode": mode, "D": D,
+                               "rows": "bf16" if dt == torch.bfloat16 else "f32", "L": L,
+                               "ids": dist, "unique": U, "us": t * 1e6, "GBps": byt / t / 1e9,
+                               "apply_us": t_a * 1e6, "apply_GBps": byt / t_a / 1e9}
+                        out.append(rec)
+                        print(json.dumps(rec))
+            del w, state
     return out
 
 

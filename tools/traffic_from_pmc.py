@@ -2,7 +2,11 @@
 """Aggregate two rocprofv3 PMC passes over `bench.py` (one with FETCH_SIZE, one with WRITE_SIZE)
 into HBM bytes per operator launch.
 
-    python tools/traffic_from_pmc.py <fetch_dir> <write_dir> <steps_run> <out.json>
+    python tools/traffic_from_pmc.py <fetch> <write> <steps_run> <out.json> [workload]
+
+<fetch> / <write>: a rocprofv3 output directory, or the per-kernel summary tools/prof_summary.py made of one
+(*_pmc.json).  [workload] (e.g. "mlperf:65536") is stored with the numbers; bench.py attaches them only to a run of
+that workload.
 
 FETCH_SIZE / WRITE_SIZE are kilobytes at the L2's memory side.  On gfx950 FETCH_SIZE tallies the
 128-byte requests of wide coalesced reads at 64 bytes, so it is doubled.  `steps_run` is
@@ -16,12 +20,12 @@ import sys
 
 # kernel-name fragment -> (operator, counts as one operator launch?)
 RULES = [
-    ("gemm_bf16x3_kernel<true, true>", "linear_forward", True),
-    ("gemm_f32_kernel<true, true>", "linear_forward", True),
-    ("gemm_bf16x3_kernel<true, false>", "linear_backward_data", True),
-    ("gemm_f32_kernel<true, false>", "linear_backward_data", True),
-    ("gemm_bf16x3_kernel<false, false>", "linear_backward_weight", True),
-    ("gemm_f32_kernel<false, false>", "linear_backward_weight", True),
+    ("gemm_bf16x3_kernel<true, true", "linear_forward", True),
+    ("gemm_f32_kernel<true, true", "linear_forward", True),
+    ("gemm_bf16x3_kernel<true, false", "linear_backward_data", True),
+    ("gemm_f32_kernel<true, false", "linear_backward_data", True),
+    ("gemm_bf16x3_kernel<false, false", "linear_backward_weight", True),
+    ("gemm_f32_kernel<false, false", "linear_backward_weight", True),
     ("reduce_slabs_kernel", "linear_backward_weight", False),
     ("skinny_k_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_fwd_kernel", "linear_forward_skinny", True),
@@ -47,24 +51,31 @@ def op_of(kernel):
     return None, False
 
 
-def read(dirname, counter):
+def read(src, counter):
     tot = collections.defaultdict(float)
     launches = collections.defaultdict(int)
     per_kernel = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(dirname + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            k = r["Kernel_Name"]
-            v = float(r["Counter_Value"]) * 1024.0
-            per_kernel[k][0] += v
-            per_kernel[k][1] += 1
-            op, anchor = op_of(k)
-            if op is None:
-                continue
-            tot[op] += v
-            if anchor:
-                launches[op] += 1
+
+    def add(k, kib, n):
+        v = kib * 1024.0
+        per_kernel[k][0] += v
+        per_kernel[k][1] += n
+        op, anchor = op_of(k)
+        if op is None:
+            return
+        tot[op] += v
+        if anchor:
+            launches[op] += n
+
+    if src.endswith(".json"):
+        for k, ctrs in json.load(open(src)).items():
+            if counter in ctrs:
+                add(k, ctrs[counter]["sum"], ctrs[counter]["dispatches"])
+    else:
+        for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    add(r["Kernel_Name"], float(r["Counter_Value"]), 1)
     return tot, launches, per_kernel
 
 
@@ -74,6 +85,7 @@ def main():
     wr, _, pk_w = read(write_dir, "WRITE_SIZE")
     res = {"note": "HBM-side bytes per operator launch; reads = FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte "
                    "read requests at 64 bytes), writes = WRITE_SIZE x 1024; separate rocprofv3 --pmc passes",
+           "workload": sys.argv[5] if len(sys.argv) > 5 else None,
            "steps_profiled": steps, "per_op_bytes_per_launch": {}, "per_op": {}, "per_kernel": {}}
     for op in sorted(set(rd) | set(wr)):
         n = max(launches.get(op, 0), 1)
