@@ -313,7 +313,7 @@ public:
         DeviceArray<int> d_ids; d_ids.upload(ids);
         DeviceArray<float> out((size_t)n * dim_);
         const std::vector<int64_t> offs = one_table(table, (size_t)n);
-        check(dlrm_vcache_read_rows(h_, d_ids.p, DLRM_I32, offs.data(), out.p, nullptr), "dlrm_vcache_read_rows");
+        check(dlrm_vcache_read_rows(h_, d_ids.p, DLRM_I32, offs.data(), out.p, nullptr, nullptr), "dlrm_vcache_read_rows");
         return out.download((size_t)n * dim_);
     }
     int64_t error_flags() {

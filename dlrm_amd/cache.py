@@ -31,6 +31,8 @@ class CacheConfig(C.Structure):
         ("d_slot_pool", C.c_void_p),
         ("max_lookup_ids", C.c_int64),
         ("writeback_dirty_only", C.c_int32),
+        ("h_row_state_store", C.POINTER(C.c_void_p)),
+        ("d_row_state_pool", C.c_void_p),
     ]
 
 
@@ -44,8 +46,10 @@ COUNTER_NAMES = ("read", "write", "hit", "miss", "evicted", "resident", "written
 
 class EmbeddingCache:
     def __init__(self, table_rows, dim, cache_size, num_slots, rows_per_page=None, evict_group=8,
-                 row_dtype=torch.float32, device="cuda", dirty_only=False, max_lookup_ids=0):
-        """dirty_only: evicted pages are copied back to the store only when mark_dirty() has flagged them
+                 row_dtype=torch.float32, device="cuda", dirty_only=False, max_lookup_ids=0, row_state=False):
+        """row_state: every row carries one float of optimizer state (row-wise Adagrad) that is read, kept and
+        written back with its page (`state_pool` on the device, `state_store[t]` on the host).
+        dirty_only: evicted pages are copied back to the store only when mark_dirty() has flagged them
         (the reference writes every victim back).  max_lookup_ids: most ids one get_emb_vectors call carries;
         every buffer is then allocated here and no later call allocates."""
         self.L = _capi.lib()
@@ -58,8 +62,8 @@ class EmbeddingCache:
         self.evict_group = evict_group
         self.num_slots = num_slots
         self.device = torch.device(device)
-        self._ptrs = []
-        self.store = []
+        self._ptrs, self._state_ptrs = [], []
+        self.store, self.state_store = [], []
         npdt = np.float32 if row_dtype == torch.float32 else np.uint16
         for r in self.table_rows:
             p = C.c_void_p()
@@ -67,6 +71,14 @@ class EmbeddingCache:
             self._ptrs.append(p)
             buf = (C.c_char * (r * dim * esz)).from_address(p.value)
             self.store.append(np.frombuffer(buf, dtype=npdt).reshape(r, dim))
+            if row_state:
+                q = C.c_void_p()
+                check(self.L.dlrm_host_alloc(C.byref(q), C.c_size_t(r * 4)))
+                C.memset(q, 0, r * 4)
+                self._state_ptrs.append(q)
+                self.state_store.append(np.frombuffer((C.c_char * (r * 4)).from_address(q.value), dtype=np.float32))
+        self.state_pool = (torch.zeros(num_slots * self.vpo, dtype=torch.float32, device=self.device)
+                           if row_state else None)
         self.pool = torch.zeros((num_slots * self.vpo, dim), dtype=row_dtype, device=self.device)
         cfg = CacheConfig()
         cfg.num_tables, cfg.dim = self.T, dim
@@ -79,6 +91,10 @@ class EmbeddingCache:
         cfg.num_slots, cfg.cache_size = num_slots, cache_size
         cfg.d_slot_pool = self.pool.data_ptr()
         cfg.max_lookup_ids, cfg.writeback_dirty_only = int(max_lookup_ids), int(bool(dirty_only))
+        if row_state:
+            self._state_arr = (C.c_void_p * self.T)(*[q.value for q in self._state_ptrs])
+            cfg.h_row_state_store = self._state_arr
+            cfg.d_row_state_pool = self.state_pool.data_ptr()
         self.h = C.c_void_p()
         check(self.L.dlrm_cache_create(C.byref(cfg), C.byref(self.h)))
 
@@ -89,10 +105,10 @@ class EmbeddingCache:
             torch.cuda.synchronize()
             self.L.dlrm_cache_destroy(self.h)
             self.h = None
-            self.store = []
-            for p in self._ptrs:
+            self.store, self.state_store = [], []
+            for p in self._ptrs + self._state_ptrs:
                 self.L.dlrm_host_free(p)
-            self._ptrs = []
+            self._ptrs, self._state_ptrs = [], []
 
     def __del__(self):
         try:

@@ -56,6 +56,8 @@ struct TableGeom {
     int64_t rows[kMaxCacheTables];
     int64_t page_base[kMaxCacheTables + 1];  // first global page id of each table
     char *store[kMaxCacheTables];            // pinned host backing store per table (device accessible)
+    float *state_store[kMaxCacheTables];     // one float per row beside it (optimizer state), or all NULL
+    int has_state;
 };
 
 struct IdLayout {
@@ -78,6 +80,7 @@ struct CacheDev {
     uint64_t *cand_key, *cand_key_sorted;
     int32_t *cand_val, *cand_val_sorted;
     char *data;
+    float *state;          // [S * vpo] the rows' optimizer state, moved with their pages; NULL = none
     int64_t S;
 };
 
@@ -95,6 +98,7 @@ struct dlrm_cache {
     hipEvent_t reclaim_ev;   // recorded behind that copy
     bool reclaim_pending;
     bool owns_pool;
+    bool owns_state;
     int protect_age;         // pages used in the last protect_age lookup calls are never victims
     int reclaim_table;       // table of a pending single-table reclaim, -1 = every table
 };
@@ -239,6 +243,15 @@ __global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheD
             const uint4 v = *reinterpret_cast<const uint4 *>(g.store[t] + page * g.page_bytes + c * 16);
             *reinterpret_cast<uint4 *>(d.data + (int64_t)s * g.page_bytes + c * 16) = v;
         }
+    }
+    if (!g.has_state) return;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < n * g.vpo;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / g.vpo, r = w - i * g.vpo;
+        const int64_t gp = d.miss_sorted[i];
+        const int t = table_of_page(g, gp);
+        const int64_t row = (gp - g.page_base[t]) * g.vpo + r;
+        if (row < g.rows[t]) d.state[(int64_t)d.page_map[gp] * g.vpo + r] = g.state_store[t][row];
     }
 }
 
@@ -450,6 +463,18 @@ __global__ __launch_bounds__(kCacheThreads) void writeback_victims_kernel(TableG
             *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) = v;
         }
     }
+    if (!g.has_state) return;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < n_cand * g.vpo;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / g.vpo, r = w - i * g.vpo;
+        if (cand_pos[i] < 0) continue;
+        const int32_t s = d.cand_val_sorted[i];
+        if (d.dirty_only && !d.slot_dirty[s]) continue;
+        const uint64_t key = d.cand_key_sorted[i];
+        const int t = (int)(key >> 58);
+        const int64_t row = ((int64_t)(uint32_t)key - g.page_base[t]) * g.vpo + r;
+        if (row < g.rows[t]) g.state_store[t][row] = d.state[(int64_t)s * g.vpo + r];
+    }
 }
 
 __global__ __launch_bounds__(kCacheThreads) void evict_kernel(TableGeom g, CacheDev d, int64_t n_cand,
@@ -521,6 +546,16 @@ __global__ __launch_bounds__(kCacheThreads) void flush_kernel(TableGeom g, Cache
             const uint4 v = *reinterpret_cast<const uint4 *>(d.data + s * g.page_bytes + c * 16);
             *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) = v;
         }
+    }
+    if (!g.has_state) return;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < d.S * g.vpo;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t s = w / g.vpo, r = w - s * g.vpo;
+        const int32_t gp = d.slot_gp[s];
+        if (gp < 0 || (d.dirty_only && !d.slot_dirty[s])) continue;
+        const int t = table_of_page(g, gp);
+        const int64_t row = ((int64_t)gp - g.page_base[t]) * g.vpo + r;
+        if (row < g.rows[t]) g.state_store[t][row] = d.state[w];
     }
 }
 
@@ -623,7 +658,17 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
                              hipGetErrorString(e));
         }
         g.store[t] = static_cast<char *>(dptr);
+        if (cfg->h_row_state_store) {
+            void *sptr = nullptr;
+            if (cfg->h_row_state_store[t] == nullptr ||
+                hipHostGetDevicePointer(&sptr, cfg->h_row_state_store[t], 0) != hipSuccess) {
+                delete c;
+                return set_error(DLRM_ERR_INVALID, "table %d: row-state store is NULL or not pinned, device-accessible host memory", t);
+            }
+            g.state_store[t] = static_cast<float *>(sptr);
+        }
     }
+    g.has_state = cfg->h_row_state_store != nullptr;
     c->total_pages = g.page_base[g.T];
     if (c->total_pages >= 0x7f7f7f7fll) {
         delete c;
@@ -654,6 +699,13 @@ extern "C" int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out)
     } else {
         c->owns_pool = true;
         if (!rc) rc = dev_alloc(&d.data, (size_t)d.S * (size_t)page_bytes);
+    }
+    if (g.has_state && cfg->d_row_state_pool) {
+        d.state = cfg->d_row_state_pool;
+    } else if (g.has_state) {
+        c->owns_state = true;
+        if (!rc) rc = dev_alloc(&d.state, (size_t)d.S * (size_t)g.vpo);
+        if (!rc) (void)hipMemset(d.state, 0, sizeof(float) * (size_t)d.S * (size_t)g.vpo);
     }
     if (!rc && (hipHostMalloc(reinterpret_cast<void **>(&c->h_reclaim), sizeof(int64_t) * S_COUNT, 0) != hipSuccess ||
                 hipEventCreateWithFlags(&c->reclaim_ev, hipEventDisableTiming) != hipSuccess))
@@ -697,6 +749,7 @@ extern "C" int dlrm_cache_destroy(dlrm_cache *c) {
     (void)hipFree(d.counters); (void)hipFree(d.k_t); (void)hipFree(d.thr_age); (void)hipFree(d.hist); (void)hipFree(d.miss); (void)hipFree(d.miss_sorted);
     (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted); (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
     if (c->owns_pool) (void)hipFree(d.data);
+    if (c->owns_state) (void)hipFree(d.state);
     (void)hipFree(c->sort_tmp);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     if (c->h_reclaim) (void)hipHostFree(c->h_reclaim);
@@ -709,6 +762,12 @@ extern "C" int dlrm_cache_storage(dlrm_cache *c, void **d_data, int64_t *total_r
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
     if (d_data) *d_data = c->d.data;
     if (total_rows) *total_rows = c->d.S * c->g.vpo;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_row_state(dlrm_cache *c, float **d_state) {
+    DLRM_REQUIRE(c != nullptr && d_state != nullptr, "NULL argument");
+    *d_state = c->d.state;
     return DLRM_OK;
 }
 

@@ -52,6 +52,8 @@ struct Geom {
     int64_t n_init[kMaxTables];                // initial pages of each table
     int64_t page_base[kMaxTables + 1];         // first global page (initial + written region) of each table
     char *store[kMaxTables];                   // pinned host store per table: (n_init + log_cap) pages
+    float *state_store[kMaxTables];            // one float per row position of that store (optimizer state), or NULL
+    int has_state;
 };
 
 struct IdLayout {
@@ -85,6 +87,8 @@ struct Dev {
     uint64_t *cand_key, *cand_key_sorted;
     int32_t *cand_val, *cand_val_sorted;
     char *data;            // slot pool [S][row_bytes]
+    float *state;          // [S] optimizer state of the resident rows; NULL = rows carry none
+    float *pend_state;     // [T][W]
     int64_t S;
 };
 
@@ -100,6 +104,7 @@ struct dlrm_vcache {
     size_t sort_tmp_bytes;
     int64_t *h_scalars;
     bool owns_pool;
+    bool owns_state;
 };
 
 namespace dlrm {
@@ -158,10 +163,21 @@ __device__ inline const char *row_source(const Geom &g, const Dev &d, int t, int
     return g.store[t] + lp * g.page_bytes + (int64_t)j * g.row_bytes;
 }
 
-__device__ inline void copy_row(const Geom &g, char *dst, const char *src, int lig) {
+// the float of optimizer state that belongs to the row stored at p (slot pool, write buffer or table t's store)
+__device__ inline float *state_at(const Geom &g, const Dev &d, int t, const char *p) {
+    if (p >= d.data && p < d.data + d.S * g.row_bytes) return d.state + (p - d.data) / g.row_bytes;
+    const char *pend_end = d.pend_data + (int64_t)g.T * g.W * g.row_bytes;
+    if (p >= d.pend_data && p < pend_end) return d.pend_state + (p - d.pend_data) / g.row_bytes;
+    return g.state_store[t] + (p - g.store[t]) / g.row_bytes;
+}
+
+// copies a row of table t between two of the places rows live in; its optimizer state goes along
+__device__ inline void copy_row(const Geom &g, const Dev &d, int t, char *dst, const char *src, int lig,
+                                bool with_state = true) {
     const int chunks = (int)(g.row_bytes / 16);
     for (int c = lig; c < chunks; c += kGroup)
         *reinterpret_cast<uint4 *>(dst + 16 * c) = *reinterpret_cast<const uint4 *>(src + 16 * c);
+    if (g.has_state && with_state && lig == 0) *state_at(g, d, t, dst) = *state_at(g, d, t, src);
 }
 
 // Ring traffic of a workgroup trip: the lanes that pop (or push) a slot number themselves in LDS, one lane moves
@@ -207,7 +223,7 @@ __device__ inline bool install_rows(const Geom &g, const Dev &d, RingTrip &ring,
     }
     s = __shfl(s, (threadIdx.x & 63) & ~(kGroup - 1), 64);
     if (s < 0) return false;
-    copy_row(g, d.data + (int64_t)s * g.row_bytes, row_source(g, d, t, r, gr), lig);
+    copy_row(g, d, t, d.data + (int64_t)s * g.row_bytes, row_source(g, d, t, r, gr), lig);
     if (lig == 0) {
         d.slot_row[s] = (int32_t)gr;
         d.slot_key[s] = 0;
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void translate_kernel(Geom g, Dev d, IdLa
 // current value of every asked row, wherever it lives (slot, write buffer or store); changes nothing
 template <typename IDX>
 __global__ __launch_bounds__(kThreads) void read_rows_kernel(Geom g, Dev d, IdLayout l, const IDX *ids, int64_t n,
-                                                              char *out) {
+                                                              char *out, float *state_out) {
     const int lig = threadIdx.x % kGroup;
     for (int64_t i = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup; i < n;
          i += (int64_t)gridDim.x * kGroupsPerBlock) {
@@ -413,7 +429,8 @@ __global__ __launch_bounds__(kThreads) void read_rows_kernel(Geom g, Dev d, IdLa
         const int64_t gr = g.row_base[t] + id;
         const int32_t s = d.row_slot[gr];
         const char *src = s >= 0 ? d.data + (int64_t)s * g.row_bytes : row_source(g, d, t, id, gr);
-        copy_row(g, out + i * g.row_bytes, src, lig);
+        copy_row(g, d, t, out + i * g.row_bytes, src, lig, false);
+        if (g.has_state && state_out && lig == 0) state_out[i] = *state_at(g, d, t, src);
     }
 }
 
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void flush_staged_kernel(Geom g, Dev d) {
         const int64_t k = d.log_head[t] + w / g.vpo;
         const int j = w % g.vpo;
         const int64_t lp = g.n_init[t] + k;
-        copy_row(g, g.store[t] + lp * g.page_bytes + (int64_t)j * g.row_bytes,
+        copy_row(g, d, t, g.store[t] + lp * g.page_bytes + (int64_t)j * g.row_bytes,
                  d.pend_data + ((int64_t)t * g.W + w) * g.row_bytes, lig);
         if (lig == 0) {
             d.log_rows[((int64_t)t * g.log_cap + k) * g.vpo + j] = (int32_t)r;
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(kThreads) void evict_kernel(Geom g, Dev d, int64_t 
                     d.row_pend[gr] = w;
                 }
             }
-            copy_row(g, dst, d.data + (int64_t)s * g.row_bytes, lig);
+            copy_row(g, d, t, dst, d.data + (int64_t)s * g.row_bytes, lig);
             if (lig == 0) {
                 // the slot's key stays non-zero until clear_keys_kernel: evictions of neighbouring rows run beside
                 // this one and take a zero key for "unlisted"
@@ -691,6 +708,8 @@ extern "C" int dlrm_vcache_destroy(dlrm_vcache *c) {
     (void)hipFree(d.flushes); (void)hipFree(d.miss); (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted);
     (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
     if (c->owns_pool) (void)hipFree(d.data);
+    if (c->owns_state) (void)hipFree(d.state);
+    (void)hipFree(d.pend_state);
     (void)hipFree(c->sort_tmp);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     delete c;
@@ -705,7 +724,8 @@ extern "C" int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **o
     DLRM_REQUIRE(cfg->table_rows != nullptr && cfg->h_table_store != nullptr, "table_rows / h_table_store is NULL");
     DLRM_REQUIRE(cfg->num_slots >= 1 && cfg->num_slots < (1ll << 31), "num_slots out of range");
     DLRM_REQUIRE(cfg->log_pages_per_table >= cfg->evict_group, "log_pages_per_table must hold at least one write");
-    const int64_t row_bytes = (int64_t)cfg->dim * 4;
+    DLRM_REQUIRE(cfg->row_dtype == DLRM_F32 || cfg->row_dtype == DLRM_BF16, "row_dtype %d", cfg->row_dtype);
+    const int64_t row_bytes = (int64_t)cfg->dim * (cfg->row_dtype == DLRM_F32 ? 4 : 2);
     DLRM_REQUIRE(row_bytes % 16 == 0, "a row (%lld bytes) must be a multiple of 16 bytes", (long long)row_bytes);
     const int64_t W = (int64_t)cfg->evict_group * cfg->rows_per_page;
     // a row that is evicted again while its first copy still waits in the write buffer takes a special path
@@ -736,7 +756,17 @@ extern "C" int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **o
                              hipGetErrorString(e));
         }
         g.store[t] = static_cast<char *>(dptr);
+        if (cfg->h_row_state_store) {
+            void *sptr = nullptr;
+            if (cfg->h_row_state_store[t] == nullptr ||
+                hipHostGetDevicePointer(&sptr, cfg->h_row_state_store[t], 0) != hipSuccess) {
+                delete c;
+                return set_error(DLRM_ERR_INVALID, "table %d: row-state store is NULL or not pinned, device-accessible host memory", t);
+            }
+            g.state_store[t] = static_cast<float *>(sptr);
+        }
     }
+    g.has_state = cfg->h_row_state_store != nullptr;
     c->total_rows = g.row_base[g.T];
     c->total_pages = g.page_base[g.T];
     if (c->total_rows >= (1ll << 31) || c->total_pages >= (1ll << 31)) {
@@ -780,6 +810,16 @@ extern "C" int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **o
     } else {
         c->owns_pool = true;
         if (!rc) rc = dev_alloc(&d.data, S * (size_t)row_bytes);
+    }
+    if (g.has_state) {
+        if (!rc) rc = dev_alloc(&d.pend_state, T * (size_t)W);
+        if (cfg->d_row_state_pool) {
+            d.state = cfg->d_row_state_pool;
+        } else {
+            c->owns_state = true;
+            if (!rc) rc = dev_alloc(&d.state, S);
+            if (!rc) (void)hipMemset(d.state, 0, sizeof(float) * S);
+        }
     }
     if (!rc && hipHostMalloc(reinterpret_cast<void **>(&c->h_scalars), sizeof(int64_t) * S_COUNT, 0) != hipSuccess)
         rc = set_error(DLRM_ERR_NOMEM, "hipHostMalloc failed");
@@ -888,8 +928,14 @@ extern "C" int dlrm_vcache_restore(dlrm_vcache *c, const void *d_ids, int32_t id
     return DLRM_OK;
 }
 
+extern "C" int dlrm_vcache_row_state(dlrm_vcache *c, float **d_state) {
+    DLRM_REQUIRE(c != nullptr && d_state != nullptr, "NULL argument");
+    *d_state = c->d.state;
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_vcache_read_rows(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
-                                     float *d_out, dlrm_stream_t stream) {
+                                     void *d_out, float *d_state_out, dlrm_stream_t stream) {
     DLRM_REQUIRE(c != nullptr && h_table_offsets != nullptr, "NULL argument");
     DLRM_REQUIRE(idx_dtype == DLRM_I32 || idx_dtype == DLRM_I64, "idx_dtype %d", idx_dtype);
     IdLayout l;
@@ -901,10 +947,10 @@ extern "C" int dlrm_vcache_read_rows(dlrm_vcache *c, const void *d_ids, int32_t 
     hipStream_t s = as_stream(stream);
     if (idx_dtype == DLRM_I64)
         hipLaunchKernelGGL(read_rows_kernel<int64_t>, dim3(kLinkBlocks), dim3(kThreads), 0, s, c->g, c->d, l,
-                           static_cast<const int64_t *>(d_ids), n, reinterpret_cast<char *>(d_out));
+                           static_cast<const int64_t *>(d_ids), n, reinterpret_cast<char *>(d_out), d_state_out);
     else
         hipLaunchKernelGGL(read_rows_kernel<int32_t>, dim3(kLinkBlocks), dim3(kThreads), 0, s, c->g, c->d, l,
-                           static_cast<const int32_t *>(d_ids), n, reinterpret_cast<char *>(d_out));
+                           static_cast<const int32_t *>(d_ids), n, reinterpret_cast<char *>(d_out), d_state_out);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

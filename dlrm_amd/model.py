@@ -232,21 +232,21 @@ class DLRM:
         wdtype = torch.bfloat16 if cfg.row_dtype == "bf16" else torch.float32
         self.cache = None
         if cache_fraction is not None:
-            if self.rw_tables or cfg.emb_optimizer != "sgd":
-                raise ValueError("the cached mode supports whole tables and the SGD row update")
+            if self.rw_tables:
+                raise ValueError("the cached mode supports whole tables")
+            adagrad = cfg.emb_optimizer == "adagrad"     # the rows' state then travels with them through the cache
             esz = 2 if cfg.row_dtype == "bf16" else 4
             rpp = cache_rows_per_page
             self.cache_policy = cache_policy
             if cache_policy == "vec":
                 from .vcache import VectorCache
-                if wdtype != torch.float32:
-                    raise ValueError("the vector-granular cache holds float32 rows")
-                rpp = 4096 // (D * 4)
+                rpp = 4096 // (D * esz)
                 per_step = self.Bg * cfg.lookups                      # new rows a table can list per step
                 cap = max(int(max(rows) * cache_fraction), 8 * rpp)
                 # listed rows plus the rows that come along with the pages of one step; evictions of all steps
                 slots = sum(min(r, (cap + 2 * per_step) * rpp) for r in rows)
-                self.cache = VectorCache(rows, D, cap, slots, log_pages_per_table=cache_log_pages, device=dev)
+                self.cache = VectorCache(rows, D, cap, slots, log_pages_per_table=cache_log_pages, device=dev,
+                                         row_dtype=wdtype, row_state=adagrad)
                 if init_tables:
                     self.cache.write_tables(seed, self.local_table_ids)
             elif cache_policy == "lru":
@@ -258,7 +258,7 @@ class DLRM:
                 # only updated pages are copied back on eviction (inference costs no device-to-host traffic);
                 # every buffer of a lookup / reclaim is allocated now (ragged batches: up to twice the nominal ids)
                 self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
-                                            row_dtype=wdtype, device=dev, dirty_only=True,
+                                            row_dtype=wdtype, device=dev, dirty_only=True, row_state=adagrad,
                                             max_lookup_ids=2 * max(self.Tl * self.Bg * cfg.lookups, 1))
                 if init_tables:
                     self.cache.write(seed, table_ids=self.local_table_ids)
@@ -280,7 +280,8 @@ class DLRM:
                                         first=ranges[lt][0] * D)
         self.opt_state = None
         if cfg.emb_optimizer == "adagrad":
-            self.opt_state = torch.zeros(max(self.total_rows, 1), dtype=torch.float32, device=dev)
+            self.opt_state = (self.cache.state_pool if self.cache is not None else
+                              torch.zeros(max(self.total_rows, 1), dtype=torch.float32, device=dev))
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
         # ---- dense parameters: one flat buffer (+ twin for gradients)

@@ -29,6 +29,9 @@ class VCacheConfig(C.Structure):
         ("h_table_store", C.POINTER(C.c_void_p)),
         ("log_pages_per_table", C.c_int64), ("num_slots", C.c_int64), ("cache_size", C.c_int64),
         ("d_slot_pool", C.c_void_p),
+        ("row_dtype", C.c_int32),
+        ("h_row_state_store", C.POINTER(C.c_void_p)),
+        ("d_row_state_pool", C.c_void_p),
     ]
 
 
@@ -42,26 +45,41 @@ COUNTER_NAMES = ("read", "write", "hit", "miss", "evicted", "resident", "listed"
 
 class VectorCache:
     def __init__(self, table_rows, dim, cache_size, num_slots, log_pages_per_table, rows_per_page=None,
-                 evict_group=8, device="cuda"):
+                 evict_group=8, device="cuda", row_dtype=torch.float32, row_state=False):
+        """row_dtype: torch.float32 (the reference's rows) or torch.bfloat16 (the store's arrays then hold the bf16
+        bit patterns as uint16).  row_state: every row carries one float of optimizer state (row-wise Adagrad)
+        that moves with it between store, write buffer and pool (`state_pool`, `state_store`)."""
         self.L = _capi.lib()
         self.L.dlrm_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.L.dlrm_host_free.argtypes = [C.c_void_p]
         self.table_rows = [int(r) for r in table_rows]
         self.T, self.dim = len(self.table_rows), dim
-        self.vpo = rows_per_page if rows_per_page else 4096 // (dim * 4)    # include/data2.h:161
+        assert row_dtype in (torch.float32, torch.bfloat16)
+        self.row_dtype = row_dtype
+        esz = 4 if row_dtype == torch.float32 else 2
+        self.vpo = rows_per_page if rows_per_page else 4096 // (dim * esz)    # include/data2.h:161
         self.evict_group, self.num_slots, self.log_pages = evict_group, num_slots, log_pages_per_table
         self.device = torch.device(device)
         self._ptrs, self.store = [], []
-        page_bytes = self.vpo * dim * 4
+        self._state_ptrs, self.state_store = [], []
+        page_bytes = self.vpo * dim * esz
         for r in self.table_rows:
             n_init = (r + self.vpo - 1) // self.vpo
             nbytes = (n_init + log_pages_per_table) * page_bytes
             p = C.c_void_p()
             check(self.L.dlrm_host_alloc(C.byref(p), C.c_size_t(nbytes)))
             self._ptrs.append(p)
-            buf = (C.c_char * (r * dim * 4)).from_address(p.value)
-            self.store.append(np.frombuffer(buf, dtype=np.float32).reshape(r, dim))
-        self.pool = torch.zeros((num_slots, dim), dtype=torch.float32, device=self.device)
+            buf = (C.c_char * (r * dim * esz)).from_address(p.value)
+            self.store.append(np.frombuffer(buf, dtype=np.float32 if esz == 4 else np.uint16).reshape(r, dim))
+            if row_state:
+                n_state = (n_init + log_pages_per_table) * self.vpo
+                q = C.c_void_p()
+                check(self.L.dlrm_host_alloc(C.byref(q), C.c_size_t(n_state * 4)))
+                C.memset(q, 0, n_state * 4)
+                self._state_ptrs.append(q)
+                self.state_store.append(np.frombuffer((C.c_char * (n_state * 4)).from_address(q.value), dtype=np.float32))
+        self.pool = torch.zeros((num_slots, dim), dtype=row_dtype, device=self.device)
+        self.state_pool = torch.zeros(num_slots, dtype=torch.float32, device=self.device) if row_state else None
         cfg = VCacheConfig()
         cfg.num_tables, cfg.dim, cfg.rows_per_page, cfg.evict_group = self.T, dim, self.vpo, evict_group
         self._rows_arr = (C.c_int64 * self.T)(*self.table_rows)
@@ -69,6 +87,11 @@ class VectorCache:
         cfg.table_rows, cfg.h_table_store = self._rows_arr, self._store_arr
         cfg.log_pages_per_table, cfg.num_slots, cfg.cache_size = log_pages_per_table, num_slots, cache_size
         cfg.d_slot_pool = self.pool.data_ptr()
+        cfg.row_dtype = _capi.F32 if esz == 4 else _capi.BF16
+        if row_state:
+            self._state_arr = (C.c_void_p * self.T)(*[q.value for q in self._state_ptrs])
+            cfg.h_row_state_store = self._state_arr
+            cfg.d_row_state_pool = self.state_pool.data_ptr()
         self.h = C.c_void_p()
         check(self.L.dlrm_vcache_create(C.byref(cfg), C.byref(self.h)))
 
@@ -77,10 +100,10 @@ class VectorCache:
             torch.cuda.synchronize()
             self.L.dlrm_vcache_destroy(self.h)
             self.h = None
-            self.store = []
-            for p in self._ptrs:
+            self.store, self.state_store = [], []
+            for p in self._ptrs + self._state_ptrs:
                 self.L.dlrm_host_free(p)
-            self._ptrs = []
+            self._ptrs, self._state_ptrs = [], []
 
     def __del__(self):
         try:
@@ -108,7 +131,8 @@ class VectorCache:
         """table_ids: the global id of each table (its random stream is keyed by it)."""
         for t, p in enumerate(self._ptrs):
             n = self.table_rows[t] * self.dim
-            check(self.L.dlrm_table_init_uniform(p, _capi.F32, C.c_int64(n),
+            check(self.L.dlrm_table_init_uniform(p, _capi.F32 if self.row_dtype == torch.float32 else _capi.BF16,
+                                                 C.c_int64(n),
                                                  C.c_uint64((seed << 20) + 7919 * (table_ids[t] + 1)),
                                                  C.c_int64(0), self._stream()))
         torch.cuda.synchronize()
@@ -130,11 +154,14 @@ class VectorCache:
                                          C.c_void_p(rows.data_ptr() if want_rows else 0), self._stream()))
         return rows
 
-    def read_rows(self, ids, table_offsets):
-        out = torch.empty((ids.numel(), self.dim), dtype=torch.float32, device=ids.device)
+    def read_rows(self, ids, table_offsets, with_state=False):
+        """Current value of every id's row wherever it lives (and, with_state, its optimizer state)."""
+        out = torch.empty((ids.numel(), self.dim), dtype=self.row_dtype, device=ids.device)
+        st = torch.zeros(ids.numel(), dtype=torch.float32, device=ids.device) if with_state else None
         check(self.L.dlrm_vcache_read_rows(self.h, C.c_void_p(ids.data_ptr()), self._dt(ids), self._offs(table_offsets),
-                                           C.c_void_p(out.data_ptr()), self._stream()))
-        return out
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(st.data_ptr() if with_state else 0),
+                                           self._stream()))
+        return (out, st) if with_state else out
 
     def state(self):
         s = VCacheState()

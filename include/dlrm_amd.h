@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1010
+#define DLRM_ABI_VERSION 1011
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -344,6 +344,12 @@ typedef struct dlrm_cache_config {
                                  /* dlrm_cache_mark_dirty has marked since they were read (inference and */
                                  /* read-mostly tables then cost no device-to-host traffic).  Residency, */
                                  /* eviction order and counters 0..5 are the same either way */
+    float *const *h_row_state_store; /* NULL, or host array[T]: pinned, device-accessible float[rows_t] per table: */
+                                 /* one float of optimizer state per row (row-wise Adagrad's sum of squared */
+                                 /* gradients) that is read, kept and written back with the row's page.  The */
+                                 /* reference's cache carries no optimizer state (its tables train with plain */
+                                 /* SGD, src/dlrmtest.cpp:505-506) */
+    float *d_row_state_pool;     /* optional caller-owned float[num_slots*rows_per_page]; NULL = the cache allocates */
 } dlrm_cache_config;
 
 typedef struct dlrm_cache_state_t {
@@ -449,6 +455,9 @@ int dlrm_cache_create(const dlrm_cache_config *cfg, dlrm_cache **out);
 int dlrm_cache_destroy(dlrm_cache *c);
 /* The slot pool as an embedding matrix: [num_slots*rows_per_page, dim] (replaces cache::get_vec(), :268). */
 int dlrm_cache_storage(dlrm_cache *c, void **d_data, int64_t *total_rows);
+/* The state of the pool's rows, float[num_slots*rows_per_page] indexed like the rows dlrm_cache_lookup returns (the
+ * d_opt_state of dlrm_sparse_opt for updates inside the pool); NULL without h_row_state_store. */
+int dlrm_cache_row_state(dlrm_cache *c, float **d_state);
 /*
  * cache::get_emb_vectors for all tables of a batch (include/data.h:247,
  * src/emb_cache.cpp:358-371): ids of table t are d_ids[h_table_offsets[t] ..
@@ -534,7 +543,7 @@ typedef struct dlrm_vcache dlrm_vcache;
 
 typedef struct dlrm_vcache_config {
     int32_t num_tables;
-    int32_t dim;                      /* float32 rows; dim * 4 must be a multiple of 16 */
+    int32_t dim;                      /* a row (dim elements of row_dtype) must be a multiple of 16 bytes */
     int32_t rows_per_page;            /* vector_page_offset = page bytes / row bytes (include/data2.h:161) */
     int32_t evict_group;              /* ws_opt: pages per write (the reference's device reports 8) */
     const int64_t *table_rows;        /* host int64[T] */
@@ -542,7 +551,13 @@ typedef struct dlrm_vcache_config {
     int64_t log_pages_per_table;
     int64_t num_slots;                /* rows of the HBM pool (listed rows + rows that came along with a page) */
     int64_t cache_size;               /* listed rows per table (src/dlrmtest2.cpp:53, :468); >= evict_group * rows_per_page */
-    void *d_slot_pool;                /* optional caller-owned [num_slots, dim] float32 device buffer */
+    void *d_slot_pool;                /* optional caller-owned [num_slots, dim] device buffer of row_dtype */
+    int32_t row_dtype;                /* DLRM_F32 (the reference's rows) | DLRM_BF16 */
+    float *const *h_row_state_store;  /* NULL, or host array[T] of pinned, device-accessible float[(pages of the */
+                                      /* store) * rows_per_page]: one float of optimizer state per row position of */
+                                      /* the store; it moves with the row (store <-> write buffer <-> slot pool). */
+                                      /* No counterpart in the reference (plain SGD, src/dlrmtest2.cpp) */
+    float *d_row_state_pool;          /* optional caller-owned float[num_slots]; NULL = the cache allocates it */
 } dlrm_vcache_config;
 
 typedef struct dlrm_vcache_state_t {
@@ -565,6 +580,8 @@ int dlrm_vcache_create(const dlrm_vcache_config *cfg, dlrm_vcache **out);
 int dlrm_vcache_destroy(dlrm_vcache *c);
 /* The slot pool [num_slots, dim]: the weight matrix for dlrm_embbag (d_table_row_offsets = NULL). */
 int dlrm_vcache_storage(dlrm_vcache *c, void **d_data, int64_t *total_rows);
+/* The state of the pool's rows, float[num_slots] (d_opt_state for updates inside the pool); NULL without a state store. */
+int dlrm_vcache_row_state(dlrm_vcache *c, float **d_state);
 /* cache2::get_emb_vectors (src/emb_cache2.cpp:686-699) for all tables of a batch: ids of table t at
  * [h_table_offsets[t], h_table_offsets[t+1]), in the caller's order (dlrmtest2 does not sort them,
  * src/dlrmtest2.cpp:63-67); d_rows_out[i] = row of id i in the slot pool (same integer type as the ids). */
@@ -576,9 +593,10 @@ int dlrm_vcache_reclaim(dlrm_vcache *c, dlrm_stream_t stream);
  * again, unlisted, with their current values.  d_rows_out optional (as in lookup). */
 int dlrm_vcache_restore(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
                         void *d_rows_out, dlrm_stream_t stream);
-/* d_out[i][dim] = current value of id i, wherever it lives (slot pool, write buffer, store).  No state change. */
+/* d_out[i][dim] (row_dtype) = current value of id i, wherever it lives (slot pool, write buffer, store), and, when
+ * d_state_out is not NULL and rows carry state, d_state_out[i] = its state.  Changes nothing in the cache. */
 int dlrm_vcache_read_rows(dlrm_vcache *c, const void *d_ids, int32_t idx_dtype, const int64_t *h_table_offsets,
-                          float *d_out, dlrm_stream_t stream);
+                          void *d_out, float *d_state_out, dlrm_stream_t stream);
 /* h_out: host int64[T][DLRM_VCACHE_NUM_COUNTERS].  Synchronises. */
 int dlrm_vcache_counters(dlrm_vcache *c, int64_t *h_out, int32_t reset_read_write, dlrm_stream_t stream);
 int dlrm_vcache_state(dlrm_vcache *c, dlrm_vcache_state_t *h_state, dlrm_stream_t stream);

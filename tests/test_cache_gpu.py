@@ -212,3 +212,38 @@ def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo):
     for t in range(T):
         assert np.array_equal(cache.store[t], expect[t]), "store of table %d" % t
     cache.close()
+
+
+@pytest.mark.parametrize("vpo", [1, 4])
+@pytest.mark.parametrize("dirty_only", [False, True])
+def test_row_state_travels_with_its_page(vpo, dirty_only):
+    """h_row_state_store: one float per row (an optimizer's state) is read into the pool's state array with the
+    row's page and written back with it; exact bookkeeping of increments through many evictions."""
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(5 + vpo)
+    rows, dim = [1000, 333, 64], 8
+    T = len(rows)
+    cache = EmbeddingCache(rows, dim, cache_size=120, num_slots=900, rows_per_page=vpo, evict_group=8,
+                           dirty_only=dirty_only, max_lookup_ids=3 * 150, row_state=True)
+    cache.write(seed=1)
+    for t in range(T):
+        cache.state_store[t][:] = np.arange(rows[t], dtype=np.float32) + 1000.0 * t
+    expect = [s.copy() for s in cache.state_store]
+    for step in range(12):
+        ids, offs = sorted_batch(rng, rows, [int(x) for x in rng.integers(1, 150, size=T)])
+        got_rows = cache.get_emb_vectors(torch.from_numpy(ids).cuda(), offs)
+        torch.cuda.synchronize()
+        st = cache.state_pool[got_rows.long()].cpu().numpy()
+        for t in range(T):
+            seg = ids[offs[t]:offs[t + 1]]
+            assert np.array_equal(st[offs[t]:offs[t + 1]], expect[t][seg]), (step, t)
+            expect[t][np.unique(seg)] += 1.0
+        cache.mark_dirty(got_rows)
+        cache.state_pool[torch.unique(got_rows.long())] += 1.0
+        cache.reclaim()
+    assert cache.counters()["evicted"].sum() > 0 and cache.state().error_flags & ~4 == 0
+    cache.flush()
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert np.array_equal(cache.state_store[t], expect[t]), "state of table %d" % t
+    cache.close()

@@ -181,3 +181,68 @@ def test_training_through_the_vector_cache_matches_oracle(oracle, kind, replay):
         offs = [0] * (t + 1) + [cfg.table_rows[t]] * (T - t)
         assert rel_err(m.cache.read_rows(ids, offs).cpu().numpy(), tables[t]) <= 1e-5
     m.cache.close()
+
+
+@pytest.mark.parametrize("policy,rows_per_page", [("lru", 1), ("lru", 4), ("vec", None)])
+@pytest.mark.parametrize("rows_t,emb_opt", [("f32", "adagrad"), ("bf16", "sgd"), ("bf16", "adagrad")])
+def test_cached_training_with_adagrad_state_and_bf16_rows(oracle, policy, rows_per_page, rows_t, emb_opt):
+    """Row-wise Adagrad and bf16 rows through both caches: a row's state is read, kept and written back with the row
+    (page-LRU: with its page; vector cache: store <-> write buffer <-> pool), so training with most rows outside HBM
+    gives the oracle's step on whole tables -- losses, predictions, and at the end every row and every state."""
+    from dlrm_amd.model import DLRM, DLRMConfig
+    from tests.test_config_shapes_gpu import make_batch_dist
+    from tests.test_model_gpu import bf16_rows_close
+    # (mean pooling and a small step keep this little model well conditioned over the 8 steps)
+    cfg = DLRMConfig(table_rows=[3000, 2500, 4000, 3500], dim=32, dense_in=13, bottom=[32, 32], top=[24, 1], lr=0.01,
+                     lookups=3, emb_optimizer=emb_opt, row_dtype=rows_t, pooling="mean")
+    B, T = 128, 4
+    kw = dict(cache_policy="vec", cache_fraction=0.12, cache_log_pages=512) if policy == "vec" else \
+        dict(cache_fraction=0.15 if rows_per_page == 1 else 0.4, cache_rows_per_page=rows_per_page)
+    m = DLRM(cfg, B, seed=5, **kw)
+    if rows_t == "bf16":
+        tables = [np.asarray(s).copy() for s in m.cache.store]          # uint16: the bf16 bit patterns
+    else:
+        tables = [oracle.table_init_uniform(r * cfg.dim, (5 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+                  for t, r in enumerate(cfg.table_rows)]
+    tro = np.concatenate([[0], np.cumsum(cfg.table_rows)])
+    state = np.zeros(int(tro[-1]), dtype=np.float32) if emb_opt == "adagrad" else None
+    Ws = [w.cpu().numpy().copy() for w in m.bottom.W + m.top.W]
+    bs = [b.cpu().numpy().copy() for b in m.bottom.b + m.top.b]
+    rng = np.random.default_rng(47)
+    for s in range(8):
+        dense, idx, off, labels = make_batch_dist(rng, cfg, B, "zipf")
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        loss = m.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(off.astype(np.int32)).cuda())
+        torch.cuda.synchronize()
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                               cfg.lr, emb_opt_state=state)
+        # bf16 rows: a row one bf16 step off moves a pooled vector by up to 2^-9 of one addend
+        tol = 1e-5 if rows_t == "f32" else 2e-3
+        assert abs(loss.item() - loss_ref) <= tol * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= tol
+        assert (m.cache.state().error_flags, int(m.err_flag.item())) == (0, 0), s
+    assert m.cache.counters()["evicted"].sum() > 0
+    # every row and every state, wherever it lives now
+    for t, r in enumerate(cfg.table_rows):
+        if policy == "vec":
+            ids = torch.arange(r, dtype=torch.int32, device="cuda")
+            offs = [0] * (t + 1) + [r] * (T - t)
+            got, got_state = m.cache.read_rows(ids, offs, with_state=True) if state is not None else \
+                (m.cache.read_rows(ids, offs), None)
+            got = got.view(torch.int16).cpu().numpy().view(np.uint16) if rows_t == "bf16" else got.cpu().numpy()
+            got_state = None if got_state is None else got_state.cpu().numpy()
+        else:
+            if t == 0:
+                m.cache.flush()
+                torch.cuda.synchronize()
+            got = np.asarray(m.cache.store[t])
+            got_state = None if state is None else np.asarray(m.cache.state_store[t])
+        if rows_t == "bf16":
+            got_f, ref_f = oracle.bf16_to_f32(got), oracle.bf16_to_f32(tables[t])
+            assert np.all(np.abs(got_f - ref_f) <= 2.0 ** -6 * np.abs(ref_f) + 1e-30)      # up to a step per update
+            assert np.mean(got == tables[t]) >= 0.99
+        else:
+            assert rel_err(got, tables[t]) <= 1e-5
+        if state is not None:
+            assert rel_err(got_state, state[tro[t]:tro[t + 1]]) <= (1e-5 if rows_t == "f32" else 2e-3)
+    m.cache.close()

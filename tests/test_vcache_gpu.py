@@ -200,3 +200,54 @@ def test_replays_reference_dlrmtest2_run(oracle, name, slots, log_pages):
             assert g == w, "batch %d" % b
     finally:
         holder["r"].vc.close()
+
+
+@pytest.mark.parametrize("rows_t", [torch.float32, torch.bfloat16])
+def test_row_values_and_state_follow_the_row(rows_t):
+    """bf16 rows (64 rows per 4096-byte page at dim 32) and one float of optimizer state per row: both follow a row
+    from the store into the pool, into the write buffer on eviction, into a newly written page, and back."""
+    from dlrm_amd.vcache import VectorCache
+    T, rows, dim = 2, 3000, 32
+    vpo = 4096 // (dim * (4 if rows_t == torch.float32 else 2))
+    gpu = VectorCache([rows] * T, dim, cache_size=8 * vpo, num_slots=T * rows, log_pages_per_table=1024, row_dtype=rows_t,
+                      row_state=True)
+    try:
+        val = [np.zeros(rows, dtype=np.float32) for _ in range(T)]       # every row holds one small integer (exact in bf16)
+        state = [np.arange(rows, dtype=np.float32) * 0.5 + 7.0 * t for t in range(T)]
+        for t in range(T):
+            if rows_t == torch.float32:
+                gpu.store[t][:] = 0.0
+            else:
+                gpu.store[t][:] = 0
+            gpu.state_store[t][:rows] = state[t]
+        rng = np.random.default_rng(3)
+        for step in range(10):
+            req = [rng.integers(0, rows, 400) for _ in range(T)]
+            ids = torch.from_numpy(np.concatenate(req).astype(np.int32)).cuda()
+            offs = [0, len(req[0]), len(req[0]) + len(req[1])]
+            got = gpu.get_emb_vectors(ids, offs)
+            torch.cuda.synchronize()
+            assert int(got.min()) >= 0
+            exp_state = np.concatenate([state[t][req[t]] for t in range(T)])
+            exp_val = np.concatenate([val[t][req[t]] for t in range(T)])
+            assert np.array_equal(gpu.state_pool[got.long()].cpu().numpy(), exp_state), step
+            assert np.array_equal(gpu.pool[got.long(), 0].float().cpu().numpy(), exp_val), step
+            uniq = torch.unique(got.long())
+            gpu.pool[uniq] += 1.0
+            gpu.state_pool[uniq] += 0.25
+            for t in range(T):
+                u = np.unique(req[t])
+                val[t][u] += 1.0
+                state[t][u] += 0.25
+            gpu.reclaim()
+            gpu.restore(ids, offs)
+        c = gpu.counters()
+        assert gpu.state().error_flags == 0 and c["write"].sum() > 0 and c["evicted"].sum() > 0
+        for t in range(T):
+            ids = torch.arange(rows, dtype=torch.int32, device="cuda")
+            offs = [0] * (t + 1) + [rows] * (T - t)
+            got, got_state = gpu.read_rows(ids, offs, with_state=True)
+            assert np.array_equal(got.float().cpu().numpy(), np.repeat(val[t][:, None], dim, axis=1)), t
+            assert np.array_equal(got_state.cpu().numpy(), state[t]), t
+    finally:
+        gpu.close()
