@@ -402,6 +402,11 @@ extern "C" int dlrm_embbag_forward(const dlrm_embbag *e, float *d_out, int64_t o
     if (avg_len < kUnroll) bpg = (int)(kUnroll / (avg_len < 0.5 ? 0.5 : avg_len) + 0.5);
     if (bpg < 1) bpg = 1;
     if (bpg > kMaxBpg) bpg = kMaxBpg;
+    // a batch too small to give every compute unit eight workgroups at that depth spreads over more groups instead
+    // (narrow rows: a wave holds 64 / G groups, so 65536 one-row bags of 256-byte rows are only 1024 workgroups at
+    // four bags per group)
+    const int64_t fill = n_bags / ((int64_t)(kFwdThreads / G) * 2048);
+    if (bpg > fill) bpg = fill < 1 ? 1 : (int)fill;
     p.bpg = bpg;
 
     hipStream_t s = as_stream(stream);
