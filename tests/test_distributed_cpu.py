@@ -111,7 +111,6 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False, backend="g
             assert m.sharded and (device == "cpu" or m.side is not None)   # exchanges on the embedding side's own stream
         dev = m.dev
         host = lambda t: t.detach().cpu().numpy()
-        loose = 1.0 if device == "cpu" else 10.0      # float32 MFMA products vs the oracle's double accumulation
         if kind == "cat":
             for b in m.bottom.b + m.top.b:
                 b.abs_()
@@ -123,8 +122,10 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False, backend="g
         bs = [host(b).copy() for b in m.bottom.b + m.top.b]
         bad = []
 
-        def close(name, a, r, rtol, atol):
-            if not np.allclose(a, r, rtol=rtol, atol=atol):
+        def close(name, a, r, tol=1e-5):
+            """the single-GPU tests' metric: largest error relative to the tensor's largest reference value"""
+            a, r = np.asarray(a, dtype=np.float64), np.asarray(r, dtype=np.float64)
+            if np.abs(a - r).max() > tol * max(np.abs(r).max(), 1e-30):
                 bad.append("%s step %d: max err %.3g (max |ref| %.3g)" % (name, step, np.abs(a - r).max(), np.abs(r).max()))
         for step in range(3 if replay else 2):           # replay: record, replay, replay with new ids
             dense, idx, off, labels = make_batch(rng, cfg, Bg)
@@ -147,14 +148,14 @@ def _worker(rank, world, port, kind, ret, device="cpu", replay=False, backend="g
             dist.all_reduce(tot)                               # per-rank shares add up to the global mean
             loss_ref, pred_ref = oracle_train_step(orc, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
                                                    cfg.lr, feature_order=m.plan.feature_order)
-            close("loss", np.float64(tot.item()), np.float64(loss_ref), 1e-5, 1e-7)
-            close("pred", host(m.pred).reshape(-1), pred_ref[sl], 1e-4, 1e-6 * loose)
+            close("loss", np.float64(tot.item()), np.float64(loss_ref))
+            close("pred", host(m.pred).reshape(-1), pred_ref[sl])
             tro = host(m.table_row_offsets)
             for lt, t in enumerate(my):
                 lo, hi = (0, cfg.table_rows[t]) if lt < m.Tl else m.plan.row_range(t, rank)
-                close("table %d" % t, host(m.weight[tro[lt]:tro[lt + 1]]), tables[t][lo:hi], 1e-5 * loose, 1e-6)
+                close("table %d" % t, host(m.weight[tro[lt]:tro[lt + 1]]), tables[t][lo:hi])
             for n, (a, r) in enumerate(zip(m.bottom.W + m.top.W + m.bottom.b + m.top.b, Ws + bs)):
-                close("dense parameter %d" % n, host(a), r, 1e-4, 1e-6 * loose)
+                close("dense parameter %d" % n, host(a), r)
         ret[rank] = "; ".join(bad) if bad else True
     finally:
         dist.destroy_process_group()
