@@ -50,4 +50,24 @@ __device__ inline uint32_t f32_to_bf16_bits(float f) {
     return u >> 16;
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Exact split of float32 values into three bf16 pieces, x = h + m + l up to 2^-27 |x| (h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m)): products of such pieces are exact in float32, which is how float32 products run on the
+// bf16 matrix pipe (six leading cross terms of the pieces, float32 accumulation).
+// a pair of float32 -> the pair's three bf16 pieces (each packed in one dword), 9 VALU operations
+__device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &l) {
+    const bf16x2 hb = __builtin_convertvector(x, bf16x2);
+    h = __builtin_bit_cast(unsigned, hb);
+    const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+    const f32x2 r1 = x - hf;
+    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+    m = __builtin_bit_cast(unsigned, mb);
+    const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;
+    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+
 }  // namespace dlrm

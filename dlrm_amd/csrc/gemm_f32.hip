@@ -357,12 +357,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 //              out of the hardware transposing read ds_read_b64_tr_b16 (two per fragment)
 // 48 KB of LDS per workgroup at 128 x 128 (12 KB per 64 of R and operand); the register budget allows two
 // workgroups per CU.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -466,20 +464,6 @@ __device__ inline void load_half_scalar(const TileAddr<RC, R> &t, int r0, int r_
         }
         xo[v] = x;
     }
-}
-
-// a pair of float32 -> the pair's three bf16 pieces (each packed in one dword), 9 VALU operations
-__device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &l) {
-    const bf16x2 hb = __builtin_convertvector(x, bf16x2);
-    h = __builtin_bit_cast(unsigned, hb);
-    const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
-    const f32x2 r1 = x - hf;
-    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-    m = __builtin_bit_cast(unsigned, mb);
-    const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
-    const f32x2 r2 = r1 - mf;
-    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-    l = __builtin_bit_cast(unsigned, lb);
 }
 
 // split the registers of one half-step and write the pieces to the three planes at `planes`

@@ -16,6 +16,34 @@ namespace dlrm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// eight consecutive float32 values -> their three bf16 pieces as MFMA operands (8 reduction elements per lane)
+struct Pieces8 {
+    bf16x8 h, m, l;
+};
+__device__ inline Pieces8 split3x8(const float4 &a, const float4 &b) {
+    unsigned h[4], m[4], l[4];
+    split3_pair(f32x2{a.x, a.y}, h[0], m[0], l[0]);
+    split3_pair(f32x2{a.z, a.w}, h[1], m[1], l[1]);
+    split3_pair(f32x2{b.x, b.y}, h[2], m[2], l[2]);
+    split3_pair(f32x2{b.z, b.w}, h[3], m[3], l[3]);
+    return Pieces8{__builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]}),
+                   __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]}),
+                   __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]})};
+}
+
+// acc += A B with float32 accuracy from the pieces of A and B: the six leading cross terms, smallest first
+__device__ inline f32x16 mfma_bf16x3(const Pieces8 &a, const Pieces8 &b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    return acc;
+}
 
 constexpr int kIntThreads = 256;
 constexpr int kIntWaves = kIntThreads / 64;
@@ -81,12 +109,23 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        for (int q = 0; q < D / 8; q++) {
-            const float4 v = *reinterpret_cast<const float4 *>(sx + row * ld + q * 8 + h * 4);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
+        if (D % 16 == 0) {
+            // float32 products on the bf16 matrix pipe (three exact pieces per value, six cross terms): 6 x 32 cycles
+            // per 16 reduction elements instead of 8 x 64 on the float32 MFMA, so that the matrix work hides
+            // behind the sample's memory traffic.  Lane (row, h) holds elements 16q + 8h .. + 7 of its row.
+            for (int q = 0; q < D / 16; q++) {
+                const float *src = sx + row * ld + q * 16 + h * 8;
+                const Pieces8 x = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
+                acc = mfma_bf16x3(x, x, acc);
+            }
+        } else {
+            for (int q = 0; q < D / 8; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(sx + row * ld + q * 8 + h * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
+            }
         }
         float *o = out + b * out_ld;
         // dense copy (feature 0) and zero padding of the row tail
@@ -172,11 +211,15 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
         }
         __builtin_amdgcn_sched_barrier(0);
         const float *go = dout + b * dout_ld;
-        // A fragments of S' = S + S^T: 4 chunks of 8 reduction (feature) indices
-        float4 fa[4];
+        // A operand S' = S + S^T (rows = output feature, reduction over the other feature, 32 deep = two steps of 16):
+        // lane (row, h) holds elements 16s + 8h .. + 7 of its row, as three bf16 pieces (float32 products on the bf16
+        // matrix pipe: 12 MFMAs of 32 cycles per block of 32 columns instead of 16 of 64)
+        Pieces8 fa[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++)   // rows >= F only feed output rows that are never stored
-            fa[q] = *reinterpret_cast<const float4 *>(ss + (row < F ? row : F - 1) * kSLd + q * 8 + h * 4);
+        for (int st = 0; st < 2; st++) {   // rows >= F only feed output rows that are never stored
+            const float *src = ss + (row < F ? row : F - 1) * kSLd + st * 16 + h * 8;
+            fa[st] = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
+        }
         float *gx = dx + b * F * D;
         for (int d0 = 0; d0 < D; d0 += 32) {
             const int d = d0 + row;
@@ -185,20 +228,21 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float a[4] = {fa[q].x, fa[q].y, fa[q].z, fa[q].w};
+            for (int st = 0; st < 2; st++) {
+                // B operand X: lane (column d, h) holds features 16s + 8h .. + 7 of its column
+                float xv[8];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int k = q * 8 + h * 4 + j;
-                    const float xv = sx[(k < F ? k : F - 1) * ld + (d_ok ? d : 0)];
-                    const float bv = (d_ok && k < F) ? xv : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc, 0, 0, 0);
+                for (int e = 0; e < 8; e++) {
+                    const int k = st * 16 + h * 8 + e;
+                    const float v = sx[(k < F ? k : F - 1) * ld + (d_ok ? d : 0)];
+                    xv[e] = (d_ok && k < F) ? v : 0.f;
                 }
+                const Pieces8 fb = split3x8(float4{xv[0], xv[1], xv[2], xv[3]}, float4{xv[4], xv[5], xv[6], xv[7]});
+                acc = mfma_bf16x3(fa[st], fb, acc);
             }
-            // The 32 x 32 block of dX goes back into the columns of the staged sample it was computed
-            // from: this lane read rows 4h..4h+3 (+8, +16, +24) of column d as B operands and writes
-            // exactly those rows, so no other lane's operand is disturbed.  The whole sample then
-            // leaves with 16-byte stores (a row per register would be 4-byte stores).
+            // The 32 x 32 block of dX goes back into the columns of the staged sample it was computed from (every
+            // operand read of these columns was issued above, by this same wave).  The whole sample then leaves
+            // with 16-byte stores (a row per register would be 4-byte stores).
             if (d_ok) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
