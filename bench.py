@@ -264,7 +264,8 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
     cm, owner = None, None
     if world > 1:
-        ids = [dcomm.unique_id() if rank == 0 else None]
+        # (--share-gpu: ranks share a device, which RCCL refuses: dlrm_comm's rehearsal transport carries the calls)
+        ids = [(dcomm.unique_id_rehearsal() if args.share_gpu else dcomm.unique_id()) if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         cm = dcomm.Comm(ids[0], rank, world)
         if args.sharding == "hybrid":
@@ -332,7 +333,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     if int(model.err_flag.item()) != 0:
         raise SystemExit("out-of-range embedding index reported by the kernels")
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt * 1e3 / args.steps
@@ -372,7 +373,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     barrier()
     dt_inf = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_inf = float(tt.item())
     infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
@@ -669,7 +670,7 @@ def main():
         barrier()
         dt_inf = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt_inf = float(tt.item())
         infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,

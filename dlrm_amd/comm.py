@@ -17,6 +17,14 @@ def unique_id():
     return bytes(buf)
 
 
+def unique_id_rehearsal():
+    """An id for the rehearsal transport (ranks of one machine exchanging through shared host memory): lets several
+    ranks share one GPU, which RCCL refuses."""
+    buf = (C.c_uint8 * ID_BYTES)()
+    check(_capi.lib().dlrm_comm_unique_id_rehearsal(buf))
+    return bytes(buf)
+
+
 class Comm:
     def __init__(self, comm_id, rank, world):
         self.L = _capi.lib()

@@ -6,11 +6,23 @@
 // parallel units (include/data2.h:150, src/emb_cache2.cpp:701-709): whole tables per rank (all-to-all of the
 // pooled vectors and of their gradients), or row ranges of a table per rank (reduce-scatter / all-gather).
 //
+// Rehearsal transport.  RCCL refuses two ranks on one device, so a box with one GPU cannot run more than one rank
+// of a host that speaks dlrm_comm.  An id drawn by dlrm_comm_unique_id_rehearsal selects a second transport with
+// the same calls and results: the ranks (processes of one machine, any devices) meet in a POSIX shared-memory
+// segment; every call drains its stream, copies this rank's send buffer to its mailbox in the segment, meets the
+// others at a barrier, builds its result from the mailboxes (sums in rank order) and copies it back.  It exists
+// so that the packing, counts and call order of a multi-rank host can be checked on one GPU; it is never chosen
+// by an id from dlrm_comm_unique_id, and it is as slow as it sounds.
+//
 // RCCL is opened at run time (dlopen) rather than linked: a process that already carries an RCCL (PyTorch
 // ships one) keeps exactly one copy.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -81,12 +93,54 @@ static int rccl_ready() {
 
 }  // namespace dlrm
 
+namespace dlrm {
+
+constexpr char kShmMagic[8] = {'D', 'L', 'R', 'M', 's', 'h', 'm', '1'};
+constexpr int kShmMaxRanks = 16;
+
+struct ShmHeader {
+    std::atomic<int> arrived;
+    std::atomic<int> generation;
+    int64_t counts[kShmMaxRanks][kShmMaxRanks];   // counts[r][p]: words rank r sends to peer p in the current call
+};
+
+struct ShmTransport {
+    char name[64];
+    ShmHeader *hdr = nullptr;
+    char *base = nullptr;       // the mapping
+    size_t map_bytes = 0, box_bytes = 0;
+    float *box(int r) const { return reinterpret_cast<float *>(base + 4096 + (size_t)r * box_bytes); }
+};
+
+}  // namespace dlrm
+
 struct dlrm_comm {
     ncclComm_t comm;
     int rank, world;
+    dlrm::ShmTransport *shm;    // rehearsal transport, else NULL
 };
 
 using namespace dlrm;
+
+static void shm_barrier(dlrm_comm *c) {
+    ShmHeader *h = c->shm->hdr;
+    const int gen = h->generation.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) == c->world - 1) {
+        h->arrived.store(0, std::memory_order_relaxed);
+        h->generation.store(gen + 1, std::memory_order_release);
+    } else {
+        while (h->generation.load(std::memory_order_acquire) == gen) usleep(50);
+    }
+}
+
+// this rank's n words into its mailbox (after everything queued on the stream before the call has run)
+static int shm_post(dlrm_comm *c, const float *d_send, int64_t n, hipStream_t s) {
+    DLRM_REQUIRE((size_t)n * 4 <= c->shm->box_bytes, "rehearsal transport: %lld words exceed the %zu-byte mailbox (set "
+                 "DLRM_COMM_REHEARSAL_MB)", (long long)n, c->shm->box_bytes);
+    DLRM_HIP(hipStreamSynchronize(s));
+    if (n) DLRM_HIP(hipMemcpy(c->shm->box(c->rank), d_send, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return DLRM_OK;
+}
 
 static_assert(DLRM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "communicator id size");
 
@@ -99,22 +153,67 @@ extern "C" int dlrm_comm_unique_id(uint8_t *id) {
     return DLRM_OK;
 }
 
+extern "C" int dlrm_comm_unique_id_rehearsal(uint8_t *id) {
+    DLRM_REQUIRE(id != nullptr, "id is NULL");
+    memset(id, 0, DLRM_COMM_ID_BYTES);
+    memcpy(id, kShmMagic, sizeof(kShmMagic));
+    static std::atomic<unsigned> serial{0};
+    snprintf(reinterpret_cast<char *>(id) + 8, 64, "/dlrm_comm_%d_%u_%llx", (int)getpid(), serial.fetch_add(1),
+             (unsigned long long)splitmix64((uint64_t)getpid() * 1000003ull + (uint64_t)clock()));
+    return DLRM_OK;
+}
+
+static int shm_init(const uint8_t *id, int32_t rank, int32_t world, dlrm_comm **out) {
+    DLRM_REQUIRE(world <= kShmMaxRanks, "rehearsal transport: at most %d ranks", kShmMaxRanks);
+    ShmTransport *t = new ShmTransport();
+    snprintf(t->name, sizeof(t->name), "%s", reinterpret_cast<const char *>(id) + 8);
+    const char *mb = getenv("DLRM_COMM_REHEARSAL_MB");
+    t->box_bytes = (size_t)(mb ? atol(mb) : 64) << 20;
+    t->map_bytes = 4096 + (size_t)world * t->box_bytes;
+    static_assert(sizeof(ShmHeader) <= 4096, "header page");
+    const int fd = shm_open(t->name, O_CREAT | O_RDWR, 0600);     // a new segment is zero-filled: counters start at 0
+    if (fd < 0 || ftruncate(fd, (off_t)t->map_bytes) != 0) {
+        if (fd >= 0) close(fd);
+        delete t;
+        return set_error(DLRM_ERR_HIP, "rehearsal transport: cannot create shared memory %s", t->name);
+    }
+    void *p = mmap(nullptr, t->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete t; return set_error(DLRM_ERR_NOMEM, "rehearsal transport: mmap failed"); }
+    t->base = static_cast<char *>(p);
+    t->hdr = reinterpret_cast<ShmHeader *>(p);
+    dlrm_comm *h = new dlrm_comm();
+    h->comm = nullptr; h->rank = rank; h->world = world; h->shm = t;
+    shm_barrier(h);                                 // everyone has mapped it
+    if (rank == 0) shm_unlink(t->name);             // the mappings keep it alive; nothing is left behind
+    shm_barrier(h);
+    *out = h;
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_comm_init(const uint8_t *id, int32_t rank, int32_t world, dlrm_comm **out) {
     DLRM_REQUIRE(id != nullptr && out != nullptr, "NULL argument");
     DLRM_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank %d of %d", rank, world);
+    if (memcmp(id, kShmMagic, sizeof(kShmMagic)) == 0) return shm_init(id, rank, world, out);
     if (int rc = rccl_ready()) return rc;
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t c = nullptr;
     DLRM_RCCL(g_rccl.CommInitRank(&c, world, u, rank));
     dlrm_comm *h = new dlrm_comm();
-    h->comm = c; h->rank = rank; h->world = world;
+    h->comm = c; h->rank = rank; h->world = world; h->shm = nullptr;
     *out = h;
     return DLRM_OK;
 }
 
 extern "C" int dlrm_comm_destroy(dlrm_comm *c) {
     if (!c) return DLRM_OK;
+    if (c->shm) {
+        munmap(c->shm->base, c->shm->map_bytes);
+        delete c->shm;
+        delete c;
+        return DLRM_OK;
+    }
     const ncclResult_t r = g_rccl.CommDestroy(c->comm);
     delete c;
     if (r != ncclSuccess) return set_error(DLRM_ERR_HIP, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
@@ -125,6 +224,21 @@ extern "C" int dlrm_comm_all_reduce_sum(dlrm_comm *c, float *d_buf, int64_t n, d
     DLRM_REQUIRE(c != nullptr && n >= 0, "bad argument");
     if (n == 0) return DLRM_OK;
     DLRM_REQUIRE(d_buf != nullptr, "d_buf is NULL");
+    if (c->shm) {
+        if (int rc = shm_post(c, d_buf, n, as_stream(stream))) return rc;
+        shm_barrier(c);
+        float *sum = new float[(size_t)n];
+        for (int64_t i = 0; i < n; i++) {
+            float a = 0.f;
+            for (int p = 0; p < c->world; p++) a += c->shm->box(p)[i];
+            sum[i] = a;
+        }
+        shm_barrier(c);                              // everyone has read every mailbox
+        const hipError_t e = hipMemcpy(d_buf, sum, (size_t)n * 4, hipMemcpyHostToDevice);
+        delete[] sum;
+        DLRM_HIP(e);
+        return DLRM_OK;
+    }
     DLRM_RCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclFloat, ncclSum, c->comm, as_stream(stream)));
     return DLRM_OK;
 }
@@ -136,6 +250,29 @@ extern "C" int dlrm_comm_all_to_all(dlrm_comm *c, const float *d_send, const int
     int64_t so = 0, ro = 0;
     for (int p = 0; p < c->world; p++)
         DLRM_REQUIRE(h_send_counts[p] >= 0 && h_recv_counts[p] >= 0, "negative count for peer %d", p);
+    if (c->shm) {
+        int64_t total = 0;
+        for (int p = 0; p < c->world; p++) {
+            c->shm->hdr->counts[c->rank][p] = h_send_counts[p];
+            total += h_send_counts[p];
+        }
+        if (int rc = shm_post(c, d_send, total, s)) return rc;
+        shm_barrier(c);
+        int rc = DLRM_OK;
+        for (int p = 0; p < c->world && !rc; p++) {
+            int64_t first = 0;
+            for (int q = 0; q < c->rank; q++) first += c->shm->hdr->counts[p][q];
+            if (c->shm->hdr->counts[p][c->rank] != h_recv_counts[p])
+                rc = set_error(DLRM_ERR_INVALID, "rank %d expects %lld words from rank %d, which sends %lld", c->rank,
+                               (long long)h_recv_counts[p], p, (long long)c->shm->hdr->counts[p][c->rank]);
+            else if (h_recv_counts[p] &&
+                     hipMemcpy(d_recv + ro, c->shm->box(p) + first, (size_t)h_recv_counts[p] * 4, hipMemcpyHostToDevice) != hipSuccess)
+                rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy to the device failed");
+            ro += h_recv_counts[p];
+        }
+        shm_barrier(c);
+        return rc;
+    }
     DLRM_RCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->world; p++) {
         ncclResult_t r = ncclSuccess;
@@ -157,6 +294,21 @@ extern "C" int dlrm_comm_reduce_scatter_sum(dlrm_comm *c, const float *d_send, f
     DLRM_REQUIRE(c != nullptr && recv_count >= 0, "bad argument");
     if (recv_count == 0) return DLRM_OK;
     DLRM_REQUIRE(d_send != nullptr && d_recv != nullptr, "NULL buffer");
+    if (c->shm) {
+        if (int rc = shm_post(c, d_send, recv_count * c->world, as_stream(stream))) return rc;
+        shm_barrier(c);
+        float *sum = new float[(size_t)recv_count];
+        for (int64_t i = 0; i < recv_count; i++) {
+            float a = 0.f;
+            for (int p = 0; p < c->world; p++) a += c->shm->box(p)[(int64_t)c->rank * recv_count + i];
+            sum[i] = a;
+        }
+        shm_barrier(c);
+        const hipError_t e = hipMemcpy(d_recv, sum, (size_t)recv_count * 4, hipMemcpyHostToDevice);
+        delete[] sum;
+        DLRM_HIP(e);
+        return DLRM_OK;
+    }
     DLRM_RCCL(g_rccl.ReduceScatter(d_send, d_recv, (size_t)recv_count, ncclFloat, ncclSum, c->comm, as_stream(stream)));
     return DLRM_OK;
 }
@@ -166,6 +318,16 @@ extern "C" int dlrm_comm_all_gather(dlrm_comm *c, const float *d_send, float *d_
     DLRM_REQUIRE(c != nullptr && send_count >= 0, "bad argument");
     if (send_count == 0) return DLRM_OK;
     DLRM_REQUIRE(d_send != nullptr && d_recv != nullptr, "NULL buffer");
+    if (c->shm) {
+        if (int rc = shm_post(c, d_send, send_count, as_stream(stream))) return rc;
+        shm_barrier(c);
+        hipError_t e = hipSuccess;
+        for (int p = 0; p < c->world && e == hipSuccess; p++)
+            e = hipMemcpy(d_recv + (int64_t)p * send_count, c->shm->box(p), (size_t)send_count * 4, hipMemcpyHostToDevice);
+        shm_barrier(c);
+        DLRM_HIP(e);
+        return DLRM_OK;
+    }
     DLRM_RCCL(g_rccl.AllGather(d_send, d_recv, (size_t)send_count, ncclFloat, c->comm, as_stream(stream)));
     return DLRM_OK;
 }

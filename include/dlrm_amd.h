@@ -624,6 +624,11 @@ typedef struct dlrm_comm dlrm_comm;
 #define DLRM_COMM_ID_BYTES 128
 /* Rank 0 draws an id and hands it to the other ranks by any means (file, environment, socket). */
 int dlrm_comm_unique_id(uint8_t *id /* [DLRM_COMM_ID_BYTES] */);
+/* An id that selects the rehearsal transport instead of RCCL: the ranks are processes of one machine that meet in
+ * shared host memory, every call drains its stream and is carried out on the host (mailboxes of 64 MiB per rank,
+ * DLRM_COMM_REHEARSAL_MB changes that; at most 16 ranks).  Same calls, same results (sums in rank order); for
+ * checking a multi-rank host on a box with fewer GPUs than ranks -- RCCL refuses two ranks on one device. */
+int dlrm_comm_unique_id_rehearsal(uint8_t *id /* [DLRM_COMM_ID_BYTES] */);
 int dlrm_comm_init(const uint8_t *id, int32_t rank, int32_t world, dlrm_comm **out);
 int dlrm_comm_destroy(dlrm_comm *c);
 /* d_buf[i] = sum over ranks, in place (the flat MLP gradient buffer). */

@@ -88,3 +88,82 @@ def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged):
     m.close()
     if cm is not None:
         cm.close()
+
+
+def _rank_worker(rank, world, comm_id, name, rw, ret):
+    """One rank of a C-hosted sharded run on GPU 0 (rehearsal transport of dlrm_comm: RCCL refuses ranks that share
+    a device): its slice of the global batch, the ids of its tables for the whole batch, compared with the oracle's
+    single-process step on the global batch."""
+    try:
+        from oracle import oracle
+        from dlrm_amd import comm
+        from dlrm_amd.cmodel import CModel
+        torch.cuda.set_device(0)
+        cfg = small_cfgs()[name]
+        Bl, T = 12, cfg.num_tables
+        Bg = Bl * world
+        cm = comm.Comm(comm_id, rank, world)
+        owner = None
+        if rw:                       # the two largest tables are split by rows over all ranks, the rest placed whole
+            big = sorted(range(T), key=lambda t: -cfg.table_rows[t])[:2]
+            rest = [t for t in range(T) if t not in big]
+            owner = [-1 if t in big else rest.index(t) % world for t in range(T)]
+        m = CModel(cfg, Bl, rank=rank, world=world, comm=cm, table_owner=owner, seed=3, idx_dtype=torch.int64)
+        m.init_dense(7)
+        Ws, bs = m.get_dense()
+        if name == "rmc1_like":
+            bs = [np.abs(b) for b in bs]
+            m.set_dense(Ws, bs)
+        tables = [oracle.table_init_uniform(r * cfg.dim, (3 << 20) + 7919 * (t + 1)).reshape(r, cfg.dim)
+                  for t, r in enumerate(cfg.table_rows)]
+        for t, (a, lo) in tables_of(m).items():          # every shard starts as the matching rows of the whole table
+            assert np.array_equal(a, tables[t][lo:lo + a.shape[0]]), "initial rows of table %d" % t
+        rng = np.random.default_rng(17)                  # every rank draws the same global batches
+        bad = []
+        for step in range(3):
+            dense, idx, off, labels = make_batch(rng, cfg, Bg, True)
+            li, lo = local_batch_ids(m, cfg, idx, off, Bg)
+            sl = slice(rank * Bl, (rank + 1) * Bl)
+            m.load_batch(torch.from_numpy(dense[sl].copy()).cuda(), torch.from_numpy(labels[sl].copy()).cuda())
+            loss = m.train_step(torch.from_numpy(li).cuda(), torch.from_numpy(lo).cuda())
+            torch.cuda.synchronize()
+            if int(m.err_flag.item()) != 0:
+                bad.append("error flag at step %d" % step)
+            tot = loss.detach().clone()
+            cm.all_reduce_sum_(tot)                      # per-rank shares add up to the global mean
+            loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom),
+                                                   cfg.lr, feature_order=m.feature_order)
+            if abs(tot.item() - loss_ref) > 1e-5 * abs(loss_ref) + 1e-7:
+                bad.append("loss step %d: %r vs %r" % (step, tot.item(), loss_ref))
+            if rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref[sl]) > 1e-5:
+                bad.append("pred step %d" % step)
+            for t, (a, lo_row) in tables_of(m).items():
+                if rel_err(a, tables[t][lo_row:lo_row + a.shape[0]]) > 1e-5:
+                    bad.append("table %d step %d" % (t, step))
+            gW, gb = m.get_dense()
+            for n, (a, r) in enumerate(zip(gW + gb, Ws + bs)):
+                if rel_err(a, r) > 1e-5:
+                    bad.append("dense parameter %d step %d" % (n, step))
+        m.close()
+        cm.close()
+        ret[rank] = "; ".join(bad) if bad else True
+    except Exception as e:       # the parent sees what went wrong instead of a bare exit code
+        import traceback
+        ret[rank] = "exception: %s\n%s" % (e, traceback.format_exc())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,rw", [("mlperf_like", False), ("mlperf_like", True), ("rmc1_like", True),
+                                     ("kaggle_like", False)])
+def test_c_hosted_sharded_step_several_ranks_one_gpu(name, rw, world):
+    """The C-hosted sharded step with 2 and 3 ranks (whole tables per rank: all-to-all of pooled vectors and their
+    gradients with per-peer counts; row-wise tables: reduce-scatter / all-gather; all-reduce of the dense
+    gradients) against the single-process oracle.  The ranks share GPU 0 and exchange through dlrm_comm's rehearsal
+    transport, which carries out the same calls in shared host memory."""
+    import torch.multiprocessing as mp
+    from dlrm_amd import comm
+    comm_id = comm.unique_id_rehearsal()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_worker, args=(world, comm_id, name, rw, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
