@@ -51,8 +51,8 @@ for w in $WHAT; do
       trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline
       pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
       pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-      # (1 warm-up + 2 timed steps + the 2 operator-timing steps bench.py appends = 5 steps under the counters)
-      python3 $ROOT/tools/traffic_from_pmc.py "$OUT/bench_FETCH_SIZE_pmc.json" "$OUT/bench_WRITE_SIZE_pmc.json" 5 \
+      # (bench.py also runs inference batches under the counters: per-launch averages only)
+      python3 $ROOT/tools/traffic_from_pmc.py "$OUT/bench_FETCH_SIZE_pmc.json" "$OUT/bench_WRITE_SIZE_pmc.json" 0 \
         "$OUT/hbm_traffic.json" mlperf:65536
       ;;
     mfma)   # matrix-pipe busy cycles of the GEMM kernels in the step, at both batch sizes, and where their waves wait

@@ -10,8 +10,8 @@ that workload.
 
 FETCH_SIZE / WRITE_SIZE are kilobytes at the L2's memory side.  On gfx950 FETCH_SIZE tallies the
 128-byte requests of wide coalesced reads at 64 bytes, so it is doubled.  `steps_run` is
-warmup + steps of the profiled command; every operator is launched the same number of times per
-step, so bytes per launch = bytes per step / launches per step."""
+warmup + steps of the profiled command when every launch belongs to a train step (0 = the run also
+launched operators outside train steps, e.g. bench.py's inference batches: only per-launch averages are kept)."""
 import collections
 import csv
 import glob
@@ -91,7 +91,9 @@ def main():
         n = max(launches.get(op, 0), 1)
         r, w = 2.0 * rd.get(op, 0.0) / n, wr.get(op, 0.0) / n
         res["per_op_bytes_per_launch"][op] = r + w
-        res["per_op"][op] = {"launches_per_step": n / steps, "read_bytes_per_launch": r, "write_bytes_per_launch": w}
+        res["per_op"][op] = {"launches": n, "read_bytes_per_launch": r, "write_bytes_per_launch": w}
+        if steps > 0:
+            res["per_op"][op]["launches_per_step"] = n / steps
     for k in sorted(set(pk_r) | set(pk_w)):
         r, n = pk_r.get(k, [0.0, 0])
         w, n2 = pk_w.get(k, [0.0, 0])
