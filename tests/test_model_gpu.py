@@ -16,8 +16,11 @@ pytestmark = pytest.mark.gpu
 def small_cfgs():
     from dlrm_amd.model import DLRMConfig
     return {
+        # (the pair products of 128-wide uniform rows are large inputs for the top MLP: with a step of 0.05 the loss
+        # jumps from 1.5 to 166 after one update and most units die, a state in which rounding differences of 1e-7
+        # grow past any tolerance within three steps; 0.001 keeps the model in the regime a real run is in)
         "mlperf_like": DLRMConfig(table_rows=[50, 3, 1000, 7, 20, 64], dim=128, dense_in=13, bottom=[64, 32, 128],
-                                  top=[96, 64, 1], lr=0.05),
+                                  top=[96, 64, 1], lr=0.001),
         "kaggle_like": DLRMConfig(table_rows=[30, 1000, 5, 80], dim=16, dense_in=13, bottom=[64, 16], top=[32, 1],
                                   lr=0.05, lookups=3),
         "rmc1_like": DLRMConfig(table_rows=[500] * 5, dim=32, dense_in=256, bottom=[128, 32], top=[32, 1],
