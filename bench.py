@@ -10,7 +10,7 @@ embeddings exchanged with RCCL all-to-all, MLP gradients all-reduced -- strong
 scaling.  A step = forward, loss, backward, fused sparse row update and dense
 SGD step on synthetic data already resident in HBM.
 
-Rank 0 prints one JSON line (see README/DESIGN for the fields).
+Rank 0 prints one JSON line.
 
 Host of the step (--host): "c" (default) = the step lives in libdlrm_amd.so behind dlrm_model_* (placement,
 streams, exchanges over dlrm_comm / RCCL, operator order: csrc/model.hip), this script only feeds batches -- what
