@@ -930,13 +930,21 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     return launch_gemm<true, false>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
+// row ranges the one-pass kernels of the narrow layers (few inputs, or one output) may cut the batch into: they
+// stream dz once, so many short ranges cost little and keep the chip busy at small batches
+static int skinny_chunk_cap(int64_t M) {
+    const int64_t c = M / 32;
+    return (int)(c < 1 ? 1 : (c > 512 ? 512 : c));
+}
+
 extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N, int32_t K, size_t *bytes) {
     DLRM_REQUIRE(bytes != nullptr && M >= 0 && N >= 1 && K >= 1, "bad arguments");
     // the split depends on the tile, which depends on the evaluation mode: room for either
     int s1 = 1, s2 = 1;
     wgrad_shape(M, N, K, DLRM_GEMM_BF16X3, &s1);
     wgrad_shape(M, N, K, DLRM_GEMM_F32_MFMA, &s2);
-    const int splits = s1 > s2 ? s1 : s2;
+    int splits = s1 > s2 ? s1 : s2;
+    if ((skinny_k_forward_ok(N, K) || N == 1) && skinny_chunk_cap(M) > splits) splits = skinny_chunk_cap(M);
     *bytes = sizeof(float) * ((size_t)splits * N * K + (size_t)splits * N) + 256;
     return DLRM_OK;
 }
@@ -960,11 +968,12 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
     const bool few_inputs = skinny_k_forward_ok(l->N, l->K);
     if (few_inputs || (l->N == 1 && gemv_backward_weight_ok(l->d_x, l->x_ld, l->K))) {
         // partial sums over row ranges, then the same fixed-order reduction as the split-batch product
-        float *dbp = l->d_db ? slabs + (size_t)splits * l->N * l->K : nullptr;
+        const int cap = skinny_chunk_cap(l->M) > splits ? skinny_chunk_cap(l->M) : splits;   // (what the workspace query sized)
+        float *dbp = l->d_db ? slabs + (size_t)cap * l->N * l->K : nullptr;
         int chunks = 0;
         const int rc = few_inputs ? skinny_k_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->N,
-                                                             l->K, splits, &chunks, s)
-                                  : gemv_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->K, splits,
+                                                             l->K, cap, &chunks, s)
+                                  : gemv_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->K, cap,
                                                          &chunks, s);
         if (rc) return rc;
         return launch_reduce(slabs, (int64_t)l->N * l->K, l->N, l->K, l->d_dw, l->dw_ld, dbp, l->d_db, chunks, s);

@@ -221,7 +221,12 @@ int skinny_k_forward(const float *x, int64_t x_ld, const float *w, int64_t w_ld,
 
 int skinny_k_backward_weight(const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, float *slabs, float *db_slabs,
                              int M, int N, int K, int max_chunks, int *chunks, hipStream_t s) {
-    int want = (int)ceil_div(M, 4 * kSkRows);               // at least four LDS trips per workgroup
+    // four LDS trips per workgroup while that still gives every compute unit four workgroups (a workgroup's trips
+    // are a chain of dependent round trips to memory: small batches want more, shorter chains), else two, else one
+    const int64_t gx = ceil_div(N, kSkThreads);
+    int trips = 4;
+    while (trips > 1 && ceil_div(M, trips * kSkRows) * gx < 1024) trips /= 2;
+    int want = (int)ceil_div(M, trips * kSkRows);
     if (want > max_chunks) want = max_chunks;
     if (want < 1) want = 1;
     const int rows_per_block = (int)(ceil_div(ceil_div(M, want), kSkRows) * kSkRows);
@@ -263,7 +268,9 @@ bool gemv_backward_weight_ok(const void *x, int64_t x_ld, int K) {
 int gemv_backward_weight(const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, float *slabs, float *db_slabs, int M,
                          int K, int max_chunks, int *chunks, hipStream_t s) {
     const int rl_n = kSkThreads / (K / 4);
-    int want = (int)ceil_div(M, 16 * rl_n);                 // at least sixteen rows per lane
+    int rows_per_lane = 16;                                 // sixteen rows per lane, fewer when that leaves most of the chip idle
+    while (rows_per_lane > 2 && ceil_div(M, rows_per_lane * rl_n) < 256) rows_per_lane /= 2;
+    int want = (int)ceil_div(M, rows_per_lane * rl_n);
     if (want > max_chunks) want = max_chunks;
     if (want < 1) want = 1;
     const int rows_per_block = (int)ceil_div(M, want);
