@@ -1,7 +1,10 @@
-// Loss forward + backward in one pass (mean reduction), single workgroup:
-// the prediction vector is one float per sample, so even the MLPerf batch
-// (65536) is 256 KiB -- far below anything worth spreading over the chip, and
-// a single workgroup gives a fixed summation order.
+// Loss value and gradient (mean reduction).  The gradient is what the backward pass waits for: one
+// thread per four samples over as many workgroups as that takes (a few microseconds at the MLPerf batch).
+// The loss VALUE is a report, nothing downstream reads it: a single workgroup sums it in a fixed order
+// (65536 samples are 64 per thread, about 40 microseconds of exp / log arithmetic on one compute unit),
+// so a host that cares launches it on a side stream (d_dpred = NULL) beside the backward pass and the
+// gradient alone (d_loss = NULL) on the critical path.  With both pointers given the two kernels run
+// one after the other on the caller's stream.
 #include "common.h"
 
 namespace dlrm {
@@ -18,6 +21,47 @@ __device__ inline float block_sum(float v, float *s) {
     if (threadIdx.x == 0)
         for (int w = 0; w < kLossThreads / 64; w++) t += s[w];
     return t;  // valid on thread 0
+}
+
+// d(loss)/d(pred) of one sample (already divided by the number of samples the mean runs over) and, in
+// `term`, the sample's loss term
+template <bool BCE>
+__device__ inline float loss_grad(float x, float t, float inv_n, int relu_mask, float &term) {
+    if constexpr (BCE) {
+        // sigmoid(x) - t without cancellation when the prediction saturates towards its label
+        // (1/(1+e^-x) rounds to exactly 1 from x = 17 on, yet the gradient there is e^-x)
+        const float e = expf(-fabsf(x));
+        const float r = e / (1.0f + e);                       // sigmoid(-|x|)
+        term = fmaxf(x, 0.f) - x * t + log1pf(e);
+        return (x >= 0.f ? (1.0f - t) - r : r - t) * inv_n;
+    } else {
+        const float d = x - t;
+        term = d * d;
+        float g = 2.0f * d * inv_n;
+        if (relu_mask && !(x > 0.f)) g = 0.f;
+        return g;
+    }
+}
+
+// gradient only: thread i owns samples 4i .. 4i+3
+template <bool BCE>
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ pred, const float *__restrict__ target,
+                                                         int64_t n, int64_t mean_over, float *__restrict__ dpred, int relu_mask) {
+    const float inv_n = 1.0f / (float)mean_over;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    float x[4], t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int64_t ic = i0 + u < n ? i0 + u : n - 1;
+        x[u] = pred[ic];
+        t[u] = target[ic];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        float term;
+        const float g = loss_grad<BCE>(x[u], t[u], inv_n, relu_mask, term);
+        if (i0 + u < n) dpred[i0 + u] = g;
+    }
 }
 
 template <bool BCE>
@@ -44,20 +88,9 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const float *__restr
         for (int u = 0; u < kU; u++) {
             const int64_t i = i0 + (int64_t)u * kLossThreads;
             if (i >= n) break;
-            float g;
-            if constexpr (BCE) {
-                // sigmoid(x) - t without cancellation when the prediction saturates towards its label
-                // (1/(1+e^-x) rounds to exactly 1 from x = 17 on, yet the gradient there is e^-x)
-                const float e = expf(-fabsf(x[u]));
-                const float r = e / (1.0f + e);                       // sigmoid(-|x|)
-                a += fmaxf(x[u], 0.f) - x[u] * t[u] + log1pf(e);
-                g = (x[u] >= 0.f ? (1.0f - t[u]) - r : r - t[u]) * inv_n;
-            } else {
-                const float d = x[u] - t[u];
-                a += d * d;
-                g = 2.0f * d * inv_n;
-                if (relu_mask && !(x[u] > 0.f)) g = 0.f;
-            }
+            float term;
+            const float g = loss_grad<BCE>(x[u], t[u], inv_n, relu_mask, term);
+            a += term;
             if (dpred) dpred[i] = g;
         }
     }
@@ -69,20 +102,30 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const float *__restr
 
 using namespace dlrm;
 
+template <bool BCE>
+static int launch_loss(const float *pred, const float *target, int64_t n, int64_t mean_over, float *loss, float *dpred,
+                       int relu_mask, hipStream_t s) {
+    if (dpred) {
+        hipLaunchKernelGGL(loss_grad_kernel<BCE>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, pred, target, n, mean_over,
+                           dpred, relu_mask);
+        DLRM_LAUNCH_CHECK();
+    }
+    if (loss) {
+        hipLaunchKernelGGL(loss_kernel<BCE>, dim3(1), dim3(kLossThreads), 0, s, pred, target, n, mean_over, loss,
+                           static_cast<float *>(nullptr), relu_mask);
+        DLRM_LAUNCH_CHECK();
+    }
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_loss_mse(const float *d_pred, const float *d_target, int64_t n, int64_t mean_over, float *d_loss,
                              float *d_dpred, int32_t relu_mask_pred, dlrm_stream_t stream) {
     DLRM_REQUIRE(n >= 1 && mean_over >= 1 && d_pred && d_target, "bad arguments");
-    hipLaunchKernelGGL(loss_kernel<false>, dim3(1), dim3(kLossThreads), 0, as_stream(stream), d_pred, d_target, n,
-                       mean_over, d_loss, d_dpred, relu_mask_pred);
-    DLRM_LAUNCH_CHECK();
-    return DLRM_OK;
+    return launch_loss<false>(d_pred, d_target, n, mean_over, d_loss, d_dpred, relu_mask_pred, as_stream(stream));
 }
 
 extern "C" int dlrm_loss_bce_logits(const float *d_logit, const float *d_target, int64_t n, int64_t mean_over,
                                     float *d_loss, float *d_dlogit, dlrm_stream_t stream) {
     DLRM_REQUIRE(n >= 1 && mean_over >= 1 && d_logit && d_target, "bad arguments");
-    hipLaunchKernelGGL(loss_kernel<true>, dim3(1), dim3(kLossThreads), 0, as_stream(stream), d_logit, d_target, n,
-                       mean_over, d_loss, d_dlogit, 0);
-    DLRM_LAUNCH_CHECK();
-    return DLRM_OK;
+    return launch_loss<true>(d_logit, d_target, n, mean_over, d_loss, d_dlogit, 0, as_stream(stream));
 }

@@ -681,11 +681,18 @@ extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const
     const dlrm_model_config &c = m->cfg;
     if (int rc = ensure_sparse_ws(m, d_indices, d_offsets, n_indices)) return rc;
     if (int rc = forward_pass(m, d_indices, d_offsets, n_indices, true, main)) return rc;
-    // loss (means over the GLOBAL batch, so the ranks' gradients add)
-    if (c.loss == DLRM_LOSS_BCE) {
-        if (int rc = dlrm_loss_bce_logits(m->pred, m->labels, m->B, m->Bg, m->loss, m->dpred, main)) return rc;
-    } else {
-        if (int rc = dlrm_loss_mse(m->pred, m->labels, m->B, m->Bg, m->loss, m->dpred, c.final_relu, main)) return rc;
+    // loss (means over the GLOBAL batch, so the ranks' gradients add): the gradient on the critical path, the
+    // value -- one workgroup's fixed-order sum, which nothing downstream reads -- beside the backward pass
+    hipStream_t side = m->s_prep ? m->s_prep : main;
+    if (int rc = wait_for(m, side, main)) return rc;    // the predictions are there
+    for (int half = 0; half < 2; half++) {
+        float *lo = half ? m->loss : nullptr, *gr = half ? nullptr : m->dpred;
+        hipStream_t s = half ? side : main;
+        if (c.loss == DLRM_LOSS_BCE) {
+            if (int rc = dlrm_loss_bce_logits(m->pred, m->labels, m->B, m->Bg, lo, gr, s)) return rc;
+        } else {
+            if (int rc = dlrm_loss_mse(m->pred, m->labels, m->B, m->Bg, lo, gr, c.final_relu, s)) return rc;
+        }
     }
     // top MLP backward, interaction backward
     if (m->dot) {
@@ -713,6 +720,7 @@ extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const
     if (m->sharded)
         if (int rc = dlrm_comm_all_reduce_sum(c.comm, m->grads, m->n_params, main)) return rc;
     if (int rc = wait_for(m, main, emb)) return rc;      // rows are updated before anyone reuses dfeat
+    if (int rc = wait_for(m, main, side)) return rc;     // the loss value is there before anyone overwrites the predictions
     return dlrm_sgd_step(m->params, m->grads, m->n_params, c.lr, main);
 }
 

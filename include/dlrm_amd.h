@@ -292,6 +292,9 @@ int dlrm_interact_dot_backward(const float *d_x, const float *d_dout, int64_t do
  * reference applies ReLU to the last layer too, src/dlrmtest.cpp:270, so pred
  * is a ReLU output and this yields the last layer's dz).
  * d_loss receives the scalar loss (device float); preds/targets have stride 1.
+ * Either of d_loss and d_dpred may be NULL.  The gradient is a chip-wide launch of a few microseconds;
+ * the scalar is summed by one workgroup in a fixed order (tens of microseconds at a batch of 65536) and
+ * nothing downstream needs it, so a host may ask for it in a call of its own on a side stream.
  * mean_over is the divisor of the mean: n on one GPU; the GLOBAL batch when the
  * batch is sharded over ranks, so that per-rank losses and gradients simply add
  * up to those of the whole batch.
