@@ -132,6 +132,25 @@ def test_linear_elementwise_error(oracle, M, N, K, gemm_mode):
     assert max(worst.values()) <= 8.0, worst
 
 
+@pytest.mark.parametrize("M,N,K", [(32805, 300, 479), (65536, 128, 256)])
+def test_linear_forward_many_tiles(oracle, M, N, K):
+    """Products with hundreds of output tiles (the batch sizes of the benchmarks): ragged rows and columns, a
+    partial last reduction step read up to the padded leading dimension, bias + ReLU; every element inside
+    |err| <= 1e-5 |ref| + 8 * 2^-24 * sum_k |a_ik b_kj| as in test_linear_elementwise_error."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y_ref = oracle.linear_forward(x, w, b, True)
+    d_x, d_w = padded(x, 128), padded(w, 128)
+    y = ops.linear_forward(d_x, d_w, torch.from_numpy(b).cuda(), True, out=padded(np.zeros((M, N), np.float32), 128))
+    torch.cuda.synchronize()
+    scale = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)[None, :]
+    assert rel_err(y.cpu().numpy(), y_ref) <= 1e-5
+    assert elementwise_excess(y.cpu().numpy(), y_ref, scale) <= 8.0
+
+
 def test_backward_weight_large_batch_split(oracle):
     """batch large enough that the reduction is split over workgroups"""
     from dlrm_amd import ops

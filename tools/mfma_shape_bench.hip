@@ -5,6 +5,10 @@
 // the numbers are an upper bound for a kernel with that inner structure.  Two MFMA shapes at equal work:
 //   shape 0  v_mfma_f32_32x32x16_bf16: per 16-deep step 12 fragment reads (16 B per lane), 24 MFMAs of 32 cycles
 //   shape 1  v_mfma_f32_16x16x32_bf16: per 32-deep step 24 fragment reads,                96 MFMAs of 16 cycles
+//   shape 2  v_mfma_f32_16x16x32_bf16 fed from 16-deep steps: the instruction's 32 reduction slots hold the 16
+//            elements of TWO cross terms (lanes 0..31 take pieces (x, y) of term one, lanes 32..63 those of term
+//            two), so three instructions cover the six terms: per 16-deep step 8 + 12 = 20 fragment reads
+//            ([a0|a1], [a0|a2]; [b0|b1], [b1|b0], [b2|b0]), 48 MFMAs of 16 cycles
 // Operands: pieces of N(0,1) values ("random"), or zeros (argument 3) -- the clock the chip holds depends on it.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/mfma_shape_bench.hip -o tools/bin/mfma_shape_bench
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const uint4 *__restrict__ im
             for (int ni = 0; ni < 2; ni++)
                 for (int r = 0; r < 16; r++) s += acc[mi][ni][r];
         out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
-    } else {
+    } else if constexpr (SHAPE == 1) {
         f32x4 acc[4][4];
         for (int mi = 0; mi < 4; mi++)
             for (int ni = 0; ni < 4; ni++)
@@ -110,6 +114,51 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const uint4 *__restrict__ im
 #pragma unroll
                     for (int t = 0; t < 6; t++)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kTA[t]], b[ni][kTB[t]], acc[mi][ni], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        float s = 0.f;
+        for (int mi = 0; mi < 4; mi++)
+            for (int ni = 0; ni < 4; ni++)
+                for (int r = 0; r < 4; r++) s += acc[mi][ni][r];
+        out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    } else {
+        f32x4 acc[4][4];
+        for (int mi = 0; mi < 4; mi++)
+            for (int ni = 0; ni < 4; ni++)
+                for (int r = 0; r < 4; r++) acc[mi][ni][r] = 0.f;
+        // lane (l & 15, g = l >> 4): groups 0, 1 read reduction elements 8 (g & 1) .. + 7 of the first piece of a
+        // pair, groups 2, 3 the same elements of the second piece
+        const int g = lane >> 4, hi = g >> 1;
+        constexpr int kPairA[2][2] = {{0, 1}, {0, 2}};              // [a0|a1], [a0|a2]
+        constexpr int kPairB[3][2] = {{0, 1}, {1, 0}, {2, 0}};      // [b0|b1], [b1|b0], [b2|b0]
+        constexpr int kUseA[3] = {0, 0, 1}, kUseB[3] = {0, 1, 2};   // a0b0+a1b1, a0b1+a1b0, a0b2+a2b0
+        for (int it = 0; it < iters; it++) {
+            int fresh = 0;
+            asm volatile("" : "+v"(fresh));
+            pa += fresh; pb += fresh;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                bf16x8 b[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        b[i][q] = *reinterpret_cast<const bf16x8 *>(pb + (hi ? kPairB[q][1] : kPairB[q][0]) * kPlane +
+                                                                     frag_off(wc * 64 + i * 16 + (lane & 15), 2 * half + (g & 1)));
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) {
+                    bf16x8 a[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+                        a[q] = *reinterpret_cast<const bf16x8 *>(pa + (hi ? kPairA[q][1] : kPairA[q][0]) * kPlane +
+                                                                  frag_off(wr * 64 + mi * 16 + (lane & 15), 2 * half + (g & 1)));
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                        for (int t = 0; t < 3; t++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kUseA[t]], b[ni][kUseB[t]], acc[mi][ni], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_s_barrier();
         }
@@ -167,10 +216,11 @@ int main(int argc, char **argv) {
     // flops per iteration and wave: 64 x 64 outputs x 32 reduction elements x 6 terms x 2
     const double flops = (double)grid * 4 * iters * 64.0 * 64.0 * 32.0 * 6.0 * 2.0;
     for (int round = 0; round < 2; round++)
-        for (int shape = 0; shape < 2; shape++) {
+        for (int shape = 0; shape < 3; shape++) {
             auto launch = [&]() {
                 if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(grid), dim3(256), 0, 0, d_img, d_out, iters);
-                else hipLaunchKernelGGL(mfma_loop<1>, dim3(grid), dim3(256), 0, 0, d_img, d_out, iters);
+                else if (shape == 1) hipLaunchKernelGGL(mfma_loop<1>, dim3(grid), dim3(256), 0, 0, d_img, d_out, iters);
+                else hipLaunchKernelGGL(mfma_loop<2>, dim3(grid), dim3(256), 0, 0, d_img, d_out, iters);
             };
             for (int i = 0; i < 5; i++) launch();
             CHECK(hipDeviceSynchronize());
@@ -183,7 +233,7 @@ int main(int argc, char **argv) {
             const double tf = flops * launches / (ms * 1e-3) / 1e12;
             printf("{\"shape\": \"%s\", \"operands\": \"%s\", \"round\": %d, \"ms_per_launch\": %.4f, \"bf16_mfma_TFLOPs\": %.1f, "
                    "\"f32_equivalent_TFLOPs\": %.1f, \"frac_of_2500\": %.3f}\n",
-                   shape == 0 ? "32x32x16" : "16x16x32", zero ? "zeros" : "pieces of N(0,1)", round, ms / launches, tf, tf / 6.0,
+                   shape == 0 ? "32x32x16" : shape == 1 ? "16x16x32" : "16x16x32 two terms per instruction", zero ? "zeros" : "pieces of N(0,1)", round, ms / launches, tf, tf / 6.0,
                    tf / 2500.0);
         }
     return 0;
