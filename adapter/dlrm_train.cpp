@@ -126,6 +126,7 @@ int main(int argc, char **argv) {
         c.lr = 0.01f; c.eps = 1e-8f; c.local_batch = B; c.rank = rank; c.world = world; c.comm = comm;
         c.table_owner = owner.empty() ? nullptr : owner.data(); c.force_exchange = force;
         c.overlap = -1; c.presort = 1; c.wgrad_stream = -1; c.seed = 0; c.init_tables = 1;
+        c.one_id_per_bag = 1;   // the synthetic batches below hold one id per table and sample (offsets[g] = g)
         dlrm_model *m = nullptr;
         ck(dlrm_model_create(&c, &m), "dlrm_model_create");
         ck(dlrm_model_init_dense(m, 0), "dlrm_model_init_dense");
@@ -188,7 +189,7 @@ int main(int argc, char **argv) {
         int32_t flag = 0;
         hk(hipMemcpy(&loss, info.d_loss, sizeof(float), hipMemcpyDeviceToHost), "loss");
         hk(hipMemcpy(&flag, info.d_error_flag, sizeof(int32_t), hipMemcpyDeviceToHost), "flag");
-        if (flag) throw std::runtime_error("an embedding index was out of range");
+        if (flag) throw std::runtime_error(flag == 2 ? "a bag did not hold exactly one id" : "an embedding index was out of range");
         printf("{\"host\": \"c++ (dlrm_model_*)\", \"config\": \"%s\", \"rank\": %d, \"world\": %d, \"global_batch\": %lld, "
                "\"steps\": %d, \"ms_per_step\": %.4f, \"samples_per_s\": %.1f, \"loss_share\": %.6f, \"exchange\": %s}\n",
                config.c_str(), rank, world, (long long)batch, steps, dt * 1e3 / steps, (double)batch * steps / dt, loss,

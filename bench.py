@@ -154,7 +154,8 @@ KERNEL_OF = {
     "embbag_forward": "embbag_fwd_group_kernel",
     "embbag_backward_update": "sparse_update_kernel + combine_runs_kernel (segmented reduction + fused optimizer)",
     "embbag_backward_prepare": "expand_pairs + rocprim radix sort (ids only; overlapped with the forward pass)",
-    "interact_dot_forward": "interact_dot_fwd_kernel",
+    "interact_dot_forward": "interact_dot_fwd_kernel (interact_dot_fwd_gather_kernel: reads the table rows itself when every "
+                            "bag holds one id)",
     "interact_dot_backward": "interact_dot_bwd_kernel",
     "linear_forward_skinny": "skinny_k_fwd_kernel / gemv_fwd_kernel (13 input columns; one output column)",
     "linear_backward_data_skinny": "gemv_bwd_data_kernel (one output column)",
@@ -176,8 +177,11 @@ def layer_shapes(cfg):
     return list(zip(bsz[:-1], bsz[1:])), list(zip(tsz[:-1], tsz[1:]))
 
 
-def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz):
-    """Algorithmic work of one step on one rank per operator class: (work, "mfma" flops | "hbm" bytes)."""
+def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gather=False):
+    """Algorithmic work of one step on one rank per operator class: (work, "mfma" flops | "hbm" bytes).
+    gather: one id per bag, the interaction's forward kernel reads the table rows itself (no EmbeddingBag forward
+    launch): it is priced with the rows, ids and offsets it reads and the copy of the block it leaves for the
+    backward pass."""
     skinny = lambda K, N: (K <= 16 and N >= 64) or N == 1
     w = {k: 0.0 for k in ("linear_forward", "linear_backward_data", "linear_backward_weight", "linear_forward_skinny",
                           "linear_backward_data_skinny", "linear_backward_weight_skinny")}
@@ -200,13 +204,16 @@ def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz):
     D, L = cfg.dim, cfg.lookups
     n_tw, n_rw = Bg * Tl * L, Bg * Trw * L
     out = {k: (v, "hbm" if k.endswith("_skinny") else "mfma") for k, v in w.items() if v}
-    out["embbag_forward"] = ((n_tw + n_rw / world) * D * row_esz + Bg * (Tl + Trw) * D * 4 + (n_tw + n_rw) * idx_esz +
-                             (Bg * (Tl + Trw) + 1) * idx_esz, "hbm")
+    if not gather:
+        out["embbag_forward"] = ((n_tw + n_rw / world) * D * row_esz + Bg * (Tl + Trw) * D * 4 + (n_tw + n_rw) * idx_esz +
+                                 (Bg * (Tl + Trw) + 1) * idx_esz, "hbm")
     out["embbag_backward_update"] = (Bg * (Tl + Trw) * D * 4 + 2 * (uniq + uniq_rw) * D * row_esz + (n_tw + n_rw) * idx_esz, "hbm")
     out["embbag_backward_prepare"] = (0.0, "hbm")
     if cfg.interaction == "dot":
         F = cfg.num_features
-        out["interact_dot_forward"] = (B * (F * D + D + F * (F - 1) // 2) * 4, "hbm")
+        # gather: the forward kernel also reads a bag's id and offset and leaves a copy of the [F, D] block
+        extra = 2 * (F - 1) * idx_esz + F * D * 4 if gather else 0
+        out["interact_dot_forward"] = (B * ((F * D + D + F * (F - 1) // 2) * 4 + extra), "hbm")
         out["interact_dot_backward"] = (B * (2 * F * D + D + F * (F - 1) // 2) * 4, "hbm")
     return out
 
@@ -271,10 +278,13 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         if args.sharding == "hybrid":
             from dlrm_amd.sharding import plan_hybrid
             owner = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows).owner
+    # one id per bag (Criteo's one-hot features): a single-GPU model reads the rows inside the interaction's forward kernel
+    gather = (world == 1 and cfg.lookups == 1 and cfg.interaction == "dot" and cfg.row_dtype != "bf16" and
+              not args.no_gather)
     model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
                    overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
                    wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
-                   gemm_mode=2 if gemm_mode == 1 else 1)
+                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather)
     model.init_dense(0)
     Tl = model.info.num_whole_tables
     Trw = model.info.num_local_tables - Tl
@@ -306,7 +316,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     def work_for(step_ids):
         u = sum(batches[i % n_batches][4][0] for i in step_ids) / max(len(step_ids), 1)
         ur = sum(batches[i % n_batches][4][1] for i in step_ids) / max(len(step_ids), 1)
-        return step_work(cfg, B, Bg, world, Tl, Trw, u, ur, 4, 2 if cfg.row_dtype == "bf16" else 4)
+        return step_work(cfg, B, Bg, world, Tl, Trw, u, ur, 4, 2 if cfg.row_dtype == "bf16" else 4, gather)
 
     launches_per_step = 80
     # warm-up; its last steps time every class to find the one that dominates a step
@@ -357,6 +367,31 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         k["traffic"] = traffic.get(k["op"]) if traffic else None
     model.enable_timing([], 0)
     emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
+    emb_note = "EmbeddingBag forward launches inside the step"
+    if emb is None and gather:
+        # no EmbeddingBag forward launch inside this step: the same batches through the kernel on its own
+        tro = torch.tensor([f for _, f, _, _ in model.local_tables] + [model.info.total_rows], dtype=torch.int64, device=dev)
+        scratch = torch.empty((Bg, Tl * cfg.dim), dtype=torch.float32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run = lambda i: ops.embbag_forward(model.weight, batches[i % n_batches][1], batches[i % n_batches][2], Bg, Tl, tro,
+                                           include_last_offset=True, out=scratch, out_ld=Tl * cfg.dim)
+        for i in range(2):
+            run(i)
+        e0.record()
+        for i in range(10):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        wk = step_work(cfg, B, Bg, world, Tl, Trw, 0, 0, 4, 4, False)["embbag_forward"][0]
+        emb = {"op": "embbag_forward", "kernel": KERNEL_OF["embbag_forward"], "bound": "hbm", "achieved": wk / (ms * 1e-3) / 1e12,
+               "peak": HBM_PEAK / 1e12, "unit": "TB/s", "frac": wk / (ms * 1e-3) / HBM_PEAK, "ms_per_step": 0.0,
+               "launches_per_step": 0.0, "avg_launch_ms": ms, "traffic": traffic.get("embbag_forward") if traffic else None,
+               "note": "not part of this step (the interaction's forward kernel reads the rows): dlrm_embbag_forward alone "
+                       "on the same batches, 10 launches"}
+        kernels.append(emb)
+        emb_note = emb["note"]
+        del scratch
 
     # forward only (inference), same batches
     n_inf = max(min(args.steps, 10), 1)
@@ -395,11 +430,13 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
                        "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
                        if gemm_mode == 1 else "float32 MFMA",
                        "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)",
+                       "embedding_lookup": "inside the interaction's forward kernel (one id per bag)" if gather else
+                       "EmbeddingBag kernel into a [B, T, D] block",
                        "parallelism": "single GPU" if world == 1 else
                        ("%s x%d + data-parallel MLP" % ("table-wise" if not Trw else
                                                         "table-wise + %d row-wise tables" % Trw, world))},
             "loss": loss_value, "cache": None, "inference": infer, "roofline": roofline,
-            "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3,
+            "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3, "embbag_hbm_gbps_from": emb_note,
             "kernels": kernels, "kernels_timed": "every class, in %d extra steps after the timed region" % n_k,
             "cpu_baseline": cpu_baseline,
         }
@@ -441,6 +478,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="single GPU, one id per bag: pool the rows with the EmbeddingBag kernel into a [B, T, D] block "
+                         "instead of reading them inside the interaction kernels")
     ap.add_argument("--no-overlap", action="store_true", help="embedding side on the caller's stream")
     ap.add_argument("--overlap", action="store_true", help="embedding side on its own stream (default for N>1)")
     ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")

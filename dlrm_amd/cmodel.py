@@ -24,7 +24,7 @@ class ModelConfig(C.Structure):
         ("local_batch", C.c_int64), ("rank", C.c_int32), ("world", C.c_int32), ("comm", C.c_void_p),
         ("table_owner", C.POINTER(C.c_int32)), ("force_exchange", C.c_int32),
         ("overlap", C.c_int32), ("presort", C.c_int32), ("wgrad_stream", C.c_int32),
-        ("seed", C.c_uint64), ("init_tables", C.c_int32),
+        ("seed", C.c_uint64), ("init_tables", C.c_int32), ("one_id_per_bag", C.c_int32),
     ]
 
 
@@ -54,7 +54,8 @@ class CModel:
     """cfg: dlrm_amd.model.DLRMConfig.  comm: dlrm_amd.comm.Communicator (sharded runs)."""
 
     def __init__(self, cfg, batch, rank=0, world=1, comm=None, table_owner=None, seed=0, force_exchange=False,
-                 overlap=-1, presort=1, wgrad_stream=-1, idx_dtype=torch.int32, device="cuda", gemm_mode=0):
+                 overlap=-1, presort=1, wgrad_stream=-1, idx_dtype=torch.int32, device="cuda", gemm_mode=0,
+                 one_id_per_bag=False):
         self.L = _capi.lib()
         self.cfg, self.B, self.rank, self.world = cfg, batch, rank, world
         self.dev = torch.device(device)
@@ -81,6 +82,7 @@ class CModel:
             c.table_owner = self._owner
         c.force_exchange, c.overlap, c.presort, c.wgrad_stream = int(force_exchange), overlap, presort, wgrad_stream
         c.seed, c.init_tables = seed, 1
+        c.one_id_per_bag = int(one_id_per_bag)
         self.h = C.c_void_p()
         check(self.L.dlrm_model_create(C.byref(c), C.byref(self.h)))
         info = ModelInfo()

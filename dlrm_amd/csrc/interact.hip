@@ -78,6 +78,44 @@ __device__ inline void sample_park(float *__restrict__ sx, const int (&lds_off)[
     for (int u = 0; u < NV; u++) *reinterpret_cast<f32x4 *>(sx + lds_off[u]) = v[u];
 }
 
+// Z = X X^T of the sample staged at sx ([32][ld], rows F.. zero) and the sample's output row: the dense copy of
+// feature 0, the strict lower triangle of Z, zeros up to out_ld
+__device__ inline void fwd_sample(const float *__restrict__ sx, int F, int D, int ld, float *__restrict__ o, int64_t out_ld,
+                                  int lane) {
+    const int row = lane & 31, h = lane >> 5;
+    const int n_pairs = F * (F - 1) / 2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    if (D % 16 == 0) {
+        // float32 products on the bf16 matrix pipe (three exact pieces per value, six cross terms): 6 x 32 cycles
+        // per 16 reduction elements instead of 8 x 64 on the float32 MFMA, so that the matrix work hides
+        // behind the sample's memory traffic.  Lane (row, h) holds elements 16q + 8h .. + 7 of its row.
+        for (int q = 0; q < D / 16; q++) {
+            const float *src = sx + row * ld + q * 16 + h * 8;
+            const Pieces8 x = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
+            acc = mfma_bf16x3(x, x, acc);
+        }
+    } else {
+        for (int q = 0; q < D / 8; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(sx + row * ld + q * 8 + h * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
+        }
+    }
+    // dense copy (feature 0) and zero padding of the row tail
+    for (int d = lane; d < D; d += 64) o[d] = sx[d];
+    for (int64_t c = D + n_pairs + lane; c < out_ld; c += 64) o[c] = 0.f;
+    // register r of lane l holds Z[i][j], i = (r&3) + 8*(r>>2) + 4*h, j = l&31
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (i < F && row < i) o[D + i * (i - 1) / 2 + row] = acc[r];
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const float *__restrict__ x, int64_t B,
                                                                         int F, int D, float *__restrict__ out,
@@ -88,9 +126,7 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
     float *sx = smem + (size_t)wave * kFP * ld;
     // rows F..31 stay zero for the whole kernel
     for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;
-    const int n_pairs = F * (F - 1) / 2;
     const int n4 = F * D / 4;
-    const int row = lane & 31, h = lane >> 5;
     const int64_t stride = (int64_t)gridDim.x * kIntWaves;
 
     int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
@@ -106,38 +142,69 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
         // next sample's loads fly behind the MFMAs (the last iteration re-reads its own sample)
         sample_fetch<NV>(x + (b + stride < B ? b + stride : b) * F * D, last_idx, lane, pre);
         __builtin_amdgcn_sched_barrier(0);
+        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dX of the sample staged at sx (pair gradients scattered into the tile ss): dX = (S + S^T) X plus the dense copy's
+// gradient on feature 0, written over the staged sample and streamed to gx with 16-byte stores
+template <int NV>
+__device__ inline void bwd_sample(float *__restrict__ sx, const float *__restrict__ ss, int F, int D, int ld,
+                                  const float *__restrict__ go, float *__restrict__ gx, const int (&lds_off)[NV], int last_idx,
+                                  int relu_mask0, int lane) {
+    const int row = lane & 31, h = lane >> 5;
+    // A operand S' = S + S^T (rows = output feature, reduction over the other feature, 32 deep = two steps of 16):
+    // lane (row, h) holds elements 16s + 8h .. + 7 of its row, as three bf16 pieces (float32 products on the bf16
+    // matrix pipe: 12 MFMAs of 32 cycles per block of 32 columns instead of 16 of 64)
+    Pieces8 fa[2];
+#pragma unroll
+    for (int st = 0; st < 2; st++) {   // rows >= F only feed output rows that are never stored
+        const float *src = ss + (row < F ? row : F - 1) * kSLd + st * 16 + h * 8;
+        fa[st] = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
+    }
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        const int d = d0 + row;
+        const bool d_ok = d < D;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        if (D % 16 == 0) {
-            // float32 products on the bf16 matrix pipe (three exact pieces per value, six cross terms): 6 x 32 cycles
-            // per 16 reduction elements instead of 8 x 64 on the float32 MFMA, so that the matrix work hides
-            // behind the sample's memory traffic.  Lane (row, h) holds elements 16q + 8h .. + 7 of its row.
-            for (int q = 0; q < D / 16; q++) {
-                const float *src = sx + row * ld + q * 16 + h * 8;
-                const Pieces8 x = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
-                acc = mfma_bf16x3(x, x, acc);
-            }
-        } else {
-            for (int q = 0; q < D / 8; q++) {
-                const float4 v = *reinterpret_cast<const float4 *>(sx + row * ld + q * 8 + h * 4);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
-            }
-        }
-        float *o = out + b * out_ld;
-        // dense copy (feature 0) and zero padding of the row tail
-        for (int d = lane; d < D; d += 64) o[d] = sx[d];
-        for (int64_t c = D + n_pairs + lane; c < out_ld; c += 64) o[c] = 0.f;
-        // register r of lane l holds Z[i][j], i = (r&3) + 8*(r>>2) + 4*h, j = l&31
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (i < F && row < i) o[D + i * (i - 1) / 2 + row] = acc[r];
+        for (int st = 0; st < 2; st++) {
+            // B operand X: lane (column d, h) holds features 16s + 8h .. + 7 of its column
+            float xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int k = st * 16 + h * 8 + e;
+                const float v = sx[(k < F ? k : F - 1) * ld + (d_ok ? d : 0)];
+                xv[e] = (d_ok && k < F) ? v : 0.f;
+            }
+            const Pieces8 fb = split3x8(float4{xv[0], xv[1], xv[2], xv[3]}, float4{xv[4], xv[5], xv[6], xv[7]});
+            acc = mfma_bf16x3(fa[st], fb, acc);
         }
-        __builtin_amdgcn_wave_barrier();
+        // The 32 x 32 block of dX goes back into the columns of the staged sample it was computed from (every
+        // operand read of these columns was issued above, by this same wave).  The whole sample then leaves
+        // with 16-byte stores (a row per register would be 4-byte stores).
+        if (d_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i >= F) continue;
+                float v = acc[r];
+                if (i == 0) {
+                    v += go[d];
+                    if (relu_mask0 && !(sx[d] > 0.f)) v = 0.f;
+                }
+                sx[i * ld + d] = v;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const int idx = u < NV - 1 ? lane + 64 * u : last_idx;
+        reinterpret_cast<f32x4 *>(gx)[idx] = *reinterpret_cast<const f32x4 *>(sx + lds_off[u]);
     }
 }
 
@@ -157,7 +224,6 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
     for (int i = lane; i < F * kSLd + 4; i += 64) ss[i] = 0.f;
     const int n_pairs = F * (F - 1) / 2;
     const int n4 = F * D / 4;
-    const int row = lane & 31, h = lane >> 5;
     const int64_t stride = (int64_t)gridDim.x * kIntWaves;
     // this lane's pair indices c = lane, lane+64, ... and their (i, j): c = i(i-1)/2 + j, 0 <= j < i
     constexpr int kMaxPairs = (kFP * (kFP - 1) / 2 + 63) / 64;   // 8
@@ -210,61 +276,136 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
             fetch_grad(nb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float *go = dout + b * dout_ld;
-        // A operand S' = S + S^T (rows = output feature, reduction over the other feature, 32 deep = two steps of 16):
-        // lane (row, h) holds elements 16s + 8h .. + 7 of its row, as three bf16 pieces (float32 products on the bf16
-        // matrix pipe: 12 MFMAs of 32 cycles per block of 32 columns instead of 16 of 64)
-        Pieces8 fa[2];
-#pragma unroll
-        for (int st = 0; st < 2; st++) {   // rows >= F only feed output rows that are never stored
-            const float *src = ss + (row < F ? row : F - 1) * kSLd + st * 16 + h * 8;
-            fa[st] = split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4));
-        }
-        float *gx = dx + b * F * D;
-        for (int d0 = 0; d0 < D; d0 += 32) {
-            const int d = d0 + row;
-            const bool d_ok = d < D;
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < 2; st++) {
-                // B operand X: lane (column d, h) holds features 16s + 8h .. + 7 of its column
-                float xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int k = st * 16 + h * 8 + e;
-                    const float v = sx[(k < F ? k : F - 1) * ld + (d_ok ? d : 0)];
-                    xv[e] = (d_ok && k < F) ? v : 0.f;
-                }
-                const Pieces8 fb = split3x8(float4{xv[0], xv[1], xv[2], xv[3]}, float4{xv[4], xv[5], xv[6], xv[7]});
-                acc = mfma_bf16x3(fa[st], fb, acc);
-            }
-            // The 32 x 32 block of dX goes back into the columns of the staged sample it was computed from (every
-            // operand read of these columns was issued above, by this same wave).  The whole sample then leaves
-            // with 16-byte stores (a row per register would be 4-byte stores).
-            if (d_ok) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (i >= F) continue;
-                    float v = acc[r];
-                    if (i == 0) {
-                        v += go[d];
-                        if (relu_mask0 && !(sx[d] > 0.f)) v = 0.f;
-                    }
-                    sx[i * ld + d] = v;
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
+        bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, dx + b * F * D, lds_off, last_idx, relu_mask0, lane);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < NV; u++) {
-            const int idx = u < NV - 1 ? lane + 64 * u : last_idx;
-            reinterpret_cast<f32x4 *>(gx)[idx] = *reinterpret_cast<const f32x4 *>(sx + lds_off[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The forward kernel with the EmbeddingBag lookup folded in, for batches whose bags hold exactly one id
+// (Criteo's one-hot categorical features): feature f >= 1 of sample b IS row indices[(f-1) B + b] of table
+// f-1, so the sample's block is gathered straight from the tables instead of being written by the EmbeddingBag
+// kernel and read back (inference saves a write and a read of [B, T, D]; a training step has the kernel leave a
+// copy of the block for the backward pass and still saves the read).  Feature 0 (the bottom MLP's output) comes
+// from x0 + b x0_ld.
+// A workgroup owns chunks of 32 consecutive samples: the chunk's ids -- T runs of 32 consecutive ids in the
+// table-major index array, one 128-byte line each -- are staged in LDS first (checked: offsets[g] == g, id inside
+// its table; a violation raises the error flag and the id counts as a zero row), then wave w takes samples
+// w, w+4, ... of the chunk.
+constexpr int kChunk = 32;
+
+struct GatherArgs {
+    const float *weight;
+    const int64_t *tro;       // [T+1] first row of every table, or NULL (all tables address rows [0, total_rows))
+    int64_t total_rows;
+    const void *indices, *offsets;
+    int T;
+    int32_t *err;
+    const float *x0;
+    int64_t x0_ld;
+};
+
+template <typename IdxT>
+__device__ inline void stage_ids(const GatherArgs &g, int64_t B, int64_t b0, int *__restrict__ sidx) {
+    const IdxT *__restrict__ idx = static_cast<const IdxT *>(g.indices);
+    const IdxT *__restrict__ off = static_cast<const IdxT *>(g.offsets);
+    for (int i = threadIdx.x; i < g.T * kChunk; i += kIntThreads) {
+        const int t = i / kChunk, j = i % kChunk;
+        const int64_t b = b0 + j;
+        int v = -1;
+        if (b < B) {
+            const int64_t pos = (int64_t)t * B + b;
+            const int64_t id = (int64_t)idx[pos];
+            const int64_t rows = g.tro ? g.tro[t + 1] - g.tro[t] : g.total_rows;
+            const bool one = (int64_t)off[pos] == pos;
+            const bool in = id >= 0 && id < rows;
+            if (one && in) v = (int)((g.tro ? g.tro[t] : 0) + id);   // row of the whole pool
+            else if (g.err) *g.err = one ? 1 : 2;
         }
-        __builtin_amdgcn_wave_barrier();
+        sidx[i] = v;
+    }
+}
+
+// Where the 16-byte vectors of a lane sit -- vector u of lane l is vector l + 64 u of the sample's [F, D] block --
+// is recomputed from the lane number wherever it is needed instead of being kept in registers (14 vectors would
+// hold 28 of them across the whole loop): `lane` goes
+// through an empty asm statement first, so the compiler cannot hoist the arithmetic out of the sample loop.
+struct VecPlace {
+    int f, col, lds;     // feature, first column, float offset in the staged sample
+};
+__device__ inline VecPlace vec_place(int lane_now, int u, int n4, int D, int ld) {   // D: a power of two
+    int i = lane_now + 64 * u;
+    if (i >= n4) i = n4 - 1;       // lanes past the end re-read the final vector and park it in the same place
+    const int e = i * 4;
+    const int f = e >> (__ffs(D) - 1);
+    VecPlace p;
+    p.f = f; p.col = e & (D - 1); p.lds = f * ld + p.col;
+    return p;
+}
+__device__ inline int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// sidx holds rows of the whole pool (table's first row + id), or -1 for a lookup that counts as a zero row
+template <int NV>
+__device__ inline void gather_fetch(const GatherArgs &g, const int *__restrict__ sidx, int j, int64_t b, int n4, int D, int ld,
+                                    int lane, f32x4 (&v)[NV]) {
+    const int lv = opaque(lane);
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const VecPlace p = vec_place(lv, u, n4, D, ld);
+        const int id = p.f == 0 ? 0 : sidx[(p.f - 1) * kChunk + j];
+        const float *src = p.f == 0 ? g.x0 + b * g.x0_ld + p.col : g.weight + (int64_t)(id < 0 ? 0 : id) * D + p.col;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(src);
+        v[u] = id < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : x;
+    }
+}
+
+template <int NV>
+__device__ inline void gather_park(float *__restrict__ sx, int n4, int D, int ld, int lane, const f32x4 (&v)[NV]) {
+    const int lv = opaque(lane);
+#pragma unroll
+    for (int u = 0; u < NV; u++) *reinterpret_cast<f32x4 *>(sx + vec_place(lv, u, n4, D, ld).lds) = v[u];
+}
+
+template <int NV, typename IdxT>
+__global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_gather_kernel(GatherArgs g, int64_t B, int F, int D,
+                                                                               float *__restrict__ out, int64_t out_ld,
+                                                                               float *__restrict__ x_copy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = D + 4;
+    float *sx = smem + (size_t)wave * kFP * ld;
+    int *sidx = reinterpret_cast<int *>(smem + (size_t)kIntWaves * kFP * ld);
+    for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;   // rows F..31 stay zero
+    const int n4 = F * D / 4;
+    const int64_t n_chunks = (B + kChunk - 1) / kChunk;
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const int64_t b0 = c * kChunk;
+        __syncthreads();     // the previous chunk's ids are no longer needed
+        stage_ids<IdxT>(g, B, b0, sidx);
+        __syncthreads();
+        f32x4 pre[NV];
+        int j = wave;
+        if (b0 + j < B) gather_fetch<NV>(g, sidx, j, b0 + j, n4, D, ld, lane, pre);
+        for (; j < kChunk && b0 + j < B; j += kIntWaves) {
+            gather_park<NV>(sx, n4, D, ld, lane, pre);
+            if (x_copy) {   // the gathered block, for a backward pass that reads it instead of gathering again
+                float *xc = x_copy + (b0 + j) * (int64_t)(F * D);
+#pragma unroll
+                for (int u = 0; u < NV; u++) reinterpret_cast<f32x4 *>(xc)[min(lane + 64 * u, n4 - 1)] = pre[u];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+            {   // the next sample's loads fly behind the MFMAs (the chunk's last one re-reads itself)
+                const int jn = (j + kIntWaves < kChunk && b0 + j + kIntWaves < B) ? j + kIntWaves : j;
+                gather_fetch<NV>(g, sidx, jn, b0 + jn, n4, D, ld, lane, pre);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_sample(sx, F, D, ld, out + (b0 + j) * out_ld, out_ld, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -333,6 +474,67 @@ extern "C" int dlrm_interact_dot_backward(const float *d_x, const float *d_dout,
         default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
     }
 #undef DLRM_INT_BWD
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+static int check_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, GatherArgs *g) {
+    DLRM_REQUIRE(e != nullptr, "embbag descriptor is NULL");
+    DLRM_REQUIRE(e->num_tables >= 1 && e->dim >= 1 && e->batch >= 0, "bad shape T=%d dim=%d batch=%lld", e->num_tables, e->dim,
+                 (long long)e->batch);
+    DLRM_REQUIRE(e->row_dtype == DLRM_F32, "the gathering interaction reads float32 rows (pool bf16 rows with dlrm_embbag_forward)");
+    DLRM_REQUIRE((e->dim & (e->dim - 1)) == 0, "the gathering interaction needs a power-of-two dim, got %d", e->dim);
+    DLRM_REQUIRE(e->idx_dtype == DLRM_I32 || e->idx_dtype == DLRM_I64, "idx_dtype %d", e->idx_dtype);
+    DLRM_REQUIRE(e->d_shard_row_begin == nullptr, "row ranges of split tables are pooled by dlrm_embbag_forward");
+    DLRM_REQUIRE(e->total_rows >= 1 && e->total_rows < (1ll << 31), "total_rows out of range");
+    DLRM_REQUIRE(e->n_indices >= (int64_t)e->num_tables * e->batch, "one id per bag needs %lld ids, got %lld",
+                 (long long)e->num_tables * e->batch, (long long)e->n_indices);
+    if (int rc = check_interact(d_x0, e->batch, e->num_tables + 1, e->dim)) return rc;
+    if (e->batch == 0) return DLRM_OK;
+    DLRM_REQUIRE(e->d_weight && e->d_indices && e->d_offsets, "NULL table / indices / offsets");
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(e->d_weight) % 16 == 0 && e->dim % 4 == 0 && x0_ld % 4 == 0 && x0_ld >= e->dim,
+                 "rows must be 16-byte aligned");
+    g->weight = static_cast<const float *>(e->d_weight); g->tro = e->d_table_row_offsets; g->total_rows = e->total_rows;
+    g->indices = e->d_indices; g->offsets = e->d_offsets; g->T = e->num_tables; g->err = e->d_error_flag;
+    g->x0 = d_x0; g->x0_ld = x0_ld;
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out,
+                                                int64_t out_ld, float *d_x_copy, dlrm_stream_t stream) {
+    GatherArgs g{};
+    if (int rc = check_gather(e, d_x0, x0_ld, &g)) return rc;
+    const int64_t B = e->batch;
+    const int F = e->num_tables + 1, D = e->dim;
+    if (B == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_out != nullptr && out_ld >= D + F * (F - 1) / 2, "out is NULL or out_ld too small");
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_x_copy) % 16 == 0, "x_copy must be 16-byte aligned");
+    const size_t lds = sizeof(float) * kIntWaves * kFP * (D + 4) + sizeof(int) * (size_t)g.T * kChunk;
+    const int64_t want = ceil_div(B, kChunk);
+    const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+    const int nv = (F * D / 4 + 63) / 64;
+    const bool i64 = e->idx_dtype == DLRM_I64;
+#define DLRM_INT_FWDG(NV)                                                                                              \
+    case NV:                                                                                                           \
+        if (i64) {                                                                                                     \
+            DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_gather_kernel<NV, int64_t>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+            hipLaunchKernelGGL((interact_dot_fwd_gather_kernel<NV, int64_t>), dim3(blocks), dim3(kIntThreads), lds,    \
+                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy);                                \
+        } else {                                                                                                       \
+            DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_gather_kernel<NV, int32_t>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+            hipLaunchKernelGGL((interact_dot_fwd_gather_kernel<NV, int32_t>), dim3(blocks), dim3(kIntThreads), lds,    \
+                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy);                                \
+        }                                                                                                              \
+        break;
+    switch (nv) {
+        DLRM_INT_FWDG(1) DLRM_INT_FWDG(2) DLRM_INT_FWDG(3) DLRM_INT_FWDG(4) DLRM_INT_FWDG(5) DLRM_INT_FWDG(6) DLRM_INT_FWDG(7)
+        DLRM_INT_FWDG(8) DLRM_INT_FWDG(9) DLRM_INT_FWDG(10) DLRM_INT_FWDG(11) DLRM_INT_FWDG(12) DLRM_INT_FWDG(13)
+        DLRM_INT_FWDG(14) DLRM_INT_FWDG(15) DLRM_INT_FWDG(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_FWDG
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

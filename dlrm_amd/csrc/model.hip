@@ -15,6 +15,8 @@
 // back.  The MLPs are data parallel (one all-reduce of the flat gradient buffer); losses are means over the
 // global batch, so per-rank gradients add.  The reference is one process; the layout follows its striping of
 // tables over parallel units (include/data2.h:150, src/emb_cache2.cpp:701-709).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -49,6 +51,7 @@ struct dlrm_model {
     int T, D, F, B, world, rank;
     int64_t Bg;
     bool sharded, dot;
+    bool gather = false;     // one id per bag: the interaction kernels read the rows themselves
     // placement
     std::vector<int> my_tables, rw_tables, feature_order;
     std::vector<std::vector<int>> tables_of_rank;
@@ -304,8 +307,10 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
                 return rc;
         }
     }
-    if (int rc = wait_for(m, emb, main)) return rc;   // earlier readers of feat and the input copies are done
-    if (int rc = emb_forward(m, idx, off, n_idx, emb)) return rc;
+    if (!m->gather) {
+        if (int rc = wait_for(m, emb, main)) return rc;   // earlier readers of feat and the input copies are done
+        if (int rc = emb_forward(m, idx, off, n_idx, emb)) return rc;
+    }
     // bottom MLP on main
     const float *x = m->x_dense;
     int64_t xl = m->x_ld;
@@ -313,11 +318,22 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
         if (int rc = linear_fwd(m, m->bot[i], x, xl, m->bot_acts[i].p, m->bot_acts[i].ld, true, main)) return rc;
         x = m->bot_acts[i].p; xl = m->bot_acts[i].ld;
     }
-    if (int rc = wait_for(m, main, emb)) return rc;
-    if (m->dot)
-        if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main,
-                           [&] { return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main); }))
+    if (m->gather) {
+        // one id per bag: feature f >= 1 of a sample is a table row, read inside the interaction kernel
+        dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
+        if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
+                // (a training step whose backward pass reads the block gets it written in place around feature 0)
+                return dlrm_interact_dot_forward_gather(&e, m->feat, m->feat_ld, m->inter, m->inter_ld,
+                                                        train ? m->feat : nullptr, main);
+            }))
             return rc;
+    } else {
+        if (int rc = wait_for(m, main, emb)) return rc;
+        if (m->dot)
+            if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main,
+                               [&] { return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main); }))
+                return rc;
+    }
     x = m->inter; xl = m->inter_ld;
     for (size_t i = 0; i < m->topl.size(); i++) {
         const bool relu = m->cfg.final_relu || i + 1 < m->topl.size();
@@ -381,6 +397,8 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     m->T = c->num_tables; m->D = c->dim; m->F = m->T + 1; m->B = (int)c->local_batch; m->world = c->world; m->rank = c->rank;
     m->Bg = (int64_t)m->B * m->world;
     m->sharded = sharded; m->dot = c->interaction == DLRM_INTERACT_DOT;
+    m->gather = c->one_id_per_bag && !sharded && m->dot && c->row_dtype == DLRM_F32 && c->num_tables + 1 <= 32 &&
+                (c->dim & (c->dim - 1)) == 0 && c->dim >= 8 && (int64_t)(c->num_tables + 1) * c->dim <= 4096;
     m->table_rows.assign(c->table_rows, c->table_rows + m->T);
     m->bottom.assign(c->bottom, c->bottom + c->n_bottom);
     m->top.assign(c->top, c->top + c->n_top);

@@ -331,6 +331,26 @@ def interact_dot_backward(x, dout, relu_mask_feature0=False, out=None):
     return out
 
 
+def interact_dot_forward_gather(weight, indices, offsets, batch, num_tables, table_row_offsets, x0, out=None, out_ld=None,
+                                error_flag=None, include_last_offset=False, x_copy=None):
+    """interact_dot_forward on x = [x0 | one row per table], the rows read straight from the tables (every bag of the
+    batch holds exactly one id).  x0: [B, D] row-major view (feature 0)."""
+    d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, _capi.POOL_SUM,
+                         include_last_offset, error_flag)
+    _require_cuda(x0, out)
+    F, D = num_tables + 1, weight.shape[1]
+    n_out = D + F * (F - 1) // 2
+    if out is None:
+        out_ld = n_out if out_ld is None else out_ld
+        out = torch.empty((batch, out_ld), dtype=torch.float32, device=weight.device)
+    if x_copy is not None:
+        _require_cuda(x_copy)
+        assert x_copy.is_contiguous() and x_copy.numel() == batch * F * D and x_copy.dtype == torch.float32
+    check(_capi.lib().dlrm_interact_dot_forward_gather(C.byref(d), _ptr(x0), C.c_int64(_ld(x0)), _ptr(out), C.c_int64(out_ld),
+                                                       _ptr(x_copy) if x_copy is not None else None, _stream()))
+    return out
+
+
 @_op
 def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None):
     _require_cuda(pred, target)

@@ -284,6 +284,24 @@ int dlrm_interact_dot_backward(const float *d_x, const float *d_dout, int64_t do
                                int32_t D, float *d_dx, int32_t relu_mask_feature0, dlrm_stream_t stream);
 
 /*
+ * The dot interaction's forward pass with the EmbeddingBag lookup folded in, for batches whose bags hold exactly
+ * ONE id each (Criteo's categorical features are one-hot): feature f >= 1 of sample b is row
+ * indices[(f-1) batch + b] of table f-1, read straight from the tables; feature 0 is d_x0 + b x0_ld (the bottom
+ * MLP's output).  The same result, bit for bit, as dlrm_embbag_forward into x[:, 1:, :] followed by
+ * dlrm_interact_dot_forward on x, without writing and re-reading the [B, T, dim] block of pooled vectors
+ * (create_emb + emb::forward + the concat, src/dlrmtest.cpp:53-86, :170-206, :265, in one pass).  `e` describes
+ * tables and ids as for dlrm_embbag_forward: float32 rows, whole tables (no d_shard_row_begin), dim a power of two,
+ * F = num_tables + 1 <= 32; pooling is irrelevant (one id).  Every bag is checked on the device: offsets[g] must
+ * equal g and the id must lie inside its table; a violation sets *d_error_flag (2: a bag that is not one id, 1: id
+ * out of range) and the lookup counts as a zero row.
+ * If d_x_copy != NULL the kernel also writes the gathered block x [B, F, dim] (dense) there, for a backward pass
+ * through dlrm_interact_dot_backward (d_x_copy may be the buffer d_x0 points into: feature 0 is rewritten with
+ * itself); NULL (inference) saves that write.
+ */
+int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,
+                                     float *d_x_copy, dlrm_stream_t stream);
+
+/*
  * Loss forward + backward in one pass, mean reduction over n predictions.
  *   mse : torch::mse_loss (src/dlrmtest.cpp:522);  d_dpred = 2 (pred - target) / n
  *   bce : binary cross entropy with logits (MLPerf DLRM loss; not in the
@@ -694,6 +712,11 @@ typedef struct dlrm_model_config {
     int32_t wgrad_stream;        /* weight gradients on their own stream: 1 / 0, -1 = when local_batch <= 32768 */
     uint64_t seed;               /* tables: uniform [0,1), table t seeded (seed << 20) + 7919 (t + 1) */
     int32_t init_tables;         /* 0 = leave the table memory as allocated (the caller fills it) */
+    int32_t one_id_per_bag;      /* promise: every bag of every batch holds exactly one id (one-hot features).  A */
+                                 /* single-GPU model with the dot interaction and float32 rows then reads the rows */
+                                 /* inside the interaction's forward kernel (dlrm_interact_dot_forward_gather) instead */
+                                 /* of pooling them into a [B, T, dim] block first; a batch that breaks the promise raises */
+                                 /* *d_error_flag (2) and its offending bags count as zero rows */
 } dlrm_model_config;
 
 typedef struct dlrm_model_info_t {

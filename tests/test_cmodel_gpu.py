@@ -90,6 +90,67 @@ def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged):
         cm.close()
 
 
+@pytest.mark.parametrize("shape", ["mlperf_like", "kaggle", "mlperf_wide"])
+def test_c_hosted_one_id_per_bag_reads_rows_in_the_interaction(oracle, shape):
+    """dlrm_model_config.one_id_per_bag: the interaction's forward kernel reads the table rows itself instead of a
+    pooled [B, T, dim] block (and leaves a copy of the block for the backward pass of a training step).  Same arithmetic on the same values, so predictions, loss, updated rows and dense parameters
+    equal those of the pooling model BIT FOR BIT over three steps (and inference likewise); the first step's
+    predictions also match the oracle to 1e-5.  Shapes: a small one, the exact Criteo-Kaggle model (26 tables,
+    dim 16, batch 2048) and 26 tables of dim 128 (the MLPerf feature block) at a ragged batch."""
+    from dlrm_amd.cmodel import CModel
+    from dlrm_amd.model import DLRMConfig
+    if shape == "mlperf_like":
+        cfg, B = small_cfgs()["mlperf_like"], 37
+    elif shape == "kaggle":
+        from tests.test_config_shapes_gpu import kaggle_cfg
+        cfg, B = kaggle_cfg(), 2048
+    else:
+        cfg, B = DLRMConfig(table_rows=[3, 50, 1000, 7] * 6 + [64, 20000], dim=128, dense_in=13, bottom=[64, 128],
+                            top=[64, 1], lr=0.001), 333
+    assert cfg.lookups == 1
+    T = cfg.num_tables
+    a = CModel(cfg, B, seed=3, one_id_per_bag=False)
+    b = CModel(cfg, B, seed=3, one_id_per_bag=True)
+    a.init_dense(7)
+    b.init_dense(7)
+    Ws, bs = a.get_dense()
+    tables = [a.weight[f:f + r].float().cpu().numpy().copy() for _, f, r, _ in a.local_tables]
+    rng = np.random.default_rng(23)
+    for step in range(3):
+        dense, idx, off, labels = make_batch(rng, cfg, B, False)
+        d_idx, d_off = torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(off.astype(np.int32)).cuda()
+        losses = []
+        for m in (a, b):
+            m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+            losses.append(m.train_step(d_idx, d_off).clone())
+        torch.cuda.synchronize()
+        assert int(a.err_flag.item()) == 0 and int(b.err_flag.item()) == 0
+        assert torch.equal(losses[0], losses[1])
+        assert torch.equal(a.pred, b.pred)
+        assert torch.equal(a.weight, b.weight)
+        assert torch.equal(a.params, b.params)
+        if step == 0:
+            _, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, len(cfg.bottom), cfg.lr,
+                                            feature_order=b.feature_order)
+            assert rel_err(b.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+    dense, idx, off, labels = make_batch(rng, cfg, B, False)
+    d_idx, d_off = torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(off.astype(np.int32)).cuda()
+    preds = []
+    for m in (a, b):
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        preds.append(m.forward(d_idx, d_off).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(preds[0], preds[1])
+    # a batch that breaks the promise is reported, not silently mis-pooled
+    d_off2 = d_off.clone()
+    d_off2[5] -= 1
+    b.forward(d_idx, d_off2)
+    torch.cuda.synchronize()
+    assert int(b.err_flag.item()) == 2
+    a.close()
+    b.close()
+
+
 def _rank_worker(rank, world, comm_id, name, rw, ret):
     """One rank of a C-hosted sharded run on GPU 0 (rehearsal transport of dlrm_comm: RCCL refuses ranks that share
     a device): its slice of the global batch, the ids of its tables for the whole batch, compared with the oracle's

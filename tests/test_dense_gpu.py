@@ -205,6 +205,64 @@ def test_interact_dot(oracle, B, F, D):
     assert rel_err(dxm.cpu().numpy(), dref_m) <= 1e-5
 
 
+@pytest.mark.parametrize("B,T,D,idx_dtype", [(300, 26, 128, torch.int32), (2048, 26, 16, torch.int32), (77, 3, 64, torch.int64),
+                                             (4100, 7, 32, torch.int32), (65, 31, 8, torch.int32)])
+def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtype):
+    """One id per bag: the interaction forward that reads the rows straight from the tables gives, bit for bit, what
+    EmbeddingBag forward + the interaction on its output give (same arithmetic on the same values), and its optional
+    copy of the gathered block equals the pooled block; the output matches the oracle to 1e-5.  A bag that is not one id and an id outside its table
+    raise the error flag (2 / 1) and count as zero rows."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(B + T + D)
+    rows = [int(r) for r in rng.integers(1, 500, size=T)]
+    tro = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    weight = torch.from_numpy(rng.standard_normal((int(tro[-1]), D)).astype(np.float32)).cuda()
+    idx = np.concatenate([rng.integers(0, rows[t], size=B) for t in range(T)])
+    indices = torch.from_numpy(idx).to(idx_dtype).cuda()
+    offsets = torch.arange(T * B + 1, dtype=idx_dtype, device="cuda")
+    d_tro = torch.from_numpy(tro).cuda()
+    F = T + 1
+    n_out = D + F * (F - 1) // 2
+    out_ld = (n_out + 3) // 4 * 4
+    x = torch.zeros((B, F, D), dtype=torch.float32, device="cuda")
+    x[:, 0, :] = torch.from_numpy(np.maximum(rng.standard_normal((B, D)), 0).astype(np.float32)).cuda()
+    xv = x.view(B, F * D)
+    ops.embbag_forward(weight, indices, offsets, B, T, d_tro, include_last_offset=True, out=xv[:, D:], out_ld=F * D)
+    ref_out = ops.interact_dot_forward(x, out_ld=out_ld)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    x0 = xv[:, :D]
+    out = ops.interact_dot_forward_gather(weight, indices, offsets, B, T, d_tro, x0, out_ld=out_ld, error_flag=flag,
+                                          include_last_offset=True)
+    # ... and with a copy of the gathered block, written in place around feature 0 (the hosted model's arrangement)
+    x2 = torch.zeros_like(x)
+    x2[:, 0, :] = x[:, 0, :]
+    out2 = ops.interact_dot_forward_gather(weight, indices, offsets, B, T, d_tro, x2.view(B, F * D)[:, :D], out_ld=out_ld,
+                                           error_flag=flag, include_last_offset=True, x_copy=x2)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert torch.equal(out, ref_out)
+    assert torch.equal(out2, ref_out) and torch.equal(x2, x)
+    z_ref = oracle.interact_dot_forward(x.cpu().numpy())
+    assert rel_err(out[:, :n_out].cpu().numpy(), z_ref) <= 1e-5
+    # violations: an id outside its table -> flag 1; a bag that is not exactly one id -> flag 2; both count as zero rows
+    bad = indices.clone()
+    bad[B // 2] = rows[0] + 5
+    x_bad = x.clone()
+    x_bad[B // 2, 1, :] = 0
+    out_bad = ops.interact_dot_forward_gather(weight, bad, offsets, B, T, d_tro, x0, out_ld=out_ld, error_flag=flag,
+                                              include_last_offset=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    assert torch.equal(out_bad, ops.interact_dot_forward(x_bad, out_ld=out_ld))
+    flag.zero_()
+    off2 = offsets.clone()
+    off2[(T - 1) * B + 3] -= 1
+    ops.interact_dot_forward_gather(weight, indices, off2, B, T, d_tro, x0, out_ld=out_ld, error_flag=flag,
+                                    include_last_offset=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 2
+
+
 @pytest.mark.parametrize("n", [1, 60, 2048, 65536])
 def test_losses(oracle, n):
     from dlrm_amd import ops
