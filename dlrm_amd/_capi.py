@@ -81,6 +81,14 @@ class LinearBwdDesc(C.Structure):
     ]
 
 
+class CopyItem(C.Structure):
+    _fields_ = [
+        ("d_dst", C.c_void_p), ("dst_ld", C.c_int64),
+        ("d_src", C.c_void_p), ("src_ld", C.c_int64),
+        ("rows", C.c_int64), ("cols", C.c_int64),
+    ]
+
+
 _lib = None
 
 

@@ -43,9 +43,68 @@ __global__ void copy_2d_kernel(V *__restrict__ dst, int64_t dst_ld, const V *__r
     }
 }
 
+// several strided 2-D copies in one launch: workgroups are dealt to the items in proportion to their size
+struct CopyManyArgs {
+    dlrm_copy_item item[DLRM_COPY_MAX_ITEMS];
+    int first_block[DLRM_COPY_MAX_ITEMS + 1];
+    int n;
+};
+
+template <typename V, int W>
+__global__ __launch_bounds__(256) void copy_2d_many_kernel(CopyManyArgs a) {
+    int it = 0;
+    while (it + 1 < a.n && (int)blockIdx.x >= a.first_block[it + 1]) it++;
+    const dlrm_copy_item m = a.item[it];
+    const int64_t cols = m.cols / W, n = m.rows * cols;
+    const int64_t dst_ld = m.dst_ld / W, src_ld = m.src_ld / W;
+    const int nb = a.first_block[it + 1] - a.first_block[it];
+    V *__restrict__ dst = reinterpret_cast<V *>(m.d_dst);
+    const V *__restrict__ src = reinterpret_cast<const V *>(m.d_src);
+    for (int64_t i = (int64_t)(blockIdx.x - a.first_block[it]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
 }  // namespace dlrm
 
 using namespace dlrm;
+
+extern "C" int dlrm_copy_2d_many(const dlrm_copy_item *items, int32_t n_items, dlrm_stream_t stream) {
+    DLRM_REQUIRE(n_items >= 0 && (items != nullptr || n_items == 0), "bad arguments");
+    for (int first = 0; first < n_items; first += DLRM_COPY_MAX_ITEMS) {
+        CopyManyArgs a{};
+        bool v4 = true;
+        int64_t total = 0;
+        for (int i = first; i < n_items && i < first + DLRM_COPY_MAX_ITEMS; i++) {
+            const dlrm_copy_item &m = items[i];
+            DLRM_REQUIRE(m.rows >= 0 && m.cols >= 0 && m.dst_ld >= m.cols && m.src_ld >= m.cols, "item %d: bad 2-D copy shape", i);
+            if (m.rows == 0 || m.cols == 0) continue;
+            DLRM_REQUIRE(m.d_dst != nullptr && m.d_src != nullptr, "item %d: NULL operand", i);
+            v4 = v4 && m.cols % 4 == 0 && m.dst_ld % 4 == 0 && m.src_ld % 4 == 0 &&
+                 reinterpret_cast<uintptr_t>(m.d_dst) % 16 == 0 && reinterpret_cast<uintptr_t>(m.d_src) % 16 == 0;
+            a.item[a.n++] = m;
+            total += m.rows * m.cols;
+        }
+        if (a.n == 0) continue;
+        // about 4096 workgroups in all, at least one per item
+        int blocks = 0;
+        for (int i = 0; i < a.n; i++) {
+            const int64_t elems = a.item[i].rows * a.item[i].cols / (v4 ? 4 : 1);
+            int64_t want = ceil_div(elems, 256);
+            const int64_t share = ceil_div(4096 * (a.item[i].rows * a.item[i].cols), total);
+            if (want > share) want = share;
+            if (want < 1) want = 1;
+            a.first_block[i] = blocks;
+            blocks += (int)want;
+        }
+        a.first_block[a.n] = blocks;
+        if (v4) hipLaunchKernelGGL((copy_2d_many_kernel<float4, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+        else hipLaunchKernelGGL((copy_2d_many_kernel<float, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+        DLRM_LAUNCH_CHECK();
+    }
+    return DLRM_OK;
+}
 
 extern "C" const char *dlrm_last_error(void) { return err_buf(); }
 extern "C" int dlrm_version(void) { return DLRM_ABI_VERSION; }

@@ -217,16 +217,20 @@ static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t 
     }
     if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->a2a_send, m->send_counts.data(), m->a2a_recv, m->recv_counts.data(), s))
         return rc;
-    int64_t o = 0;
-    int first = 0;
-    for (int j = 0; j < m->world; j++) {
-        const int cnt = (int)m->tables_of_rank[j].size();
-        if (cnt)
-            if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)first * D, m->feat_ld, m->a2a_recv + o, (int64_t)cnt * D, B,
-                                      (int64_t)cnt * D, s))
-                return rc;
-        o += B * cnt * D;
-        first += cnt;
+    // the block of every source rank into its columns of the feature block, one launch
+    {
+        std::vector<dlrm_copy_item> items;
+        int64_t o = 0;
+        int first = 0;
+        for (int j = 0; j < m->world; j++) {
+            const int cnt = (int)m->tables_of_rank[j].size();
+            if (cnt)
+                items.push_back(dlrm_copy_item{m->feat + m->emb_col0 + (int64_t)first * D, m->feat_ld, m->a2a_recv + o,
+                                               (int64_t)cnt * D, B, (int64_t)cnt * D});
+            o += B * cnt * D;
+            first += cnt;
+        }
+        if (int rc = dlrm_copy_2d_many(items.data(), (int32_t)items.size(), s)) return rc;
     }
     if (m->Trw) {
         dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
@@ -265,16 +269,19 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
     if (m->cfg.presort && m->s_prep)
         if (int rc = wait_for(m, s, m->s_prep)) return rc;
     if (!m->sharded) return sparse_update(m, false, idx, off, n_idx, m->dfeat + m->emb_col0, m->feat_ld, s);
-    int64_t o = 0;
-    int first = 0;
-    for (int j = 0; j < m->world; j++) {
-        const int cnt = (int)m->tables_of_rank[j].size();
-        if (cnt)
-            if (int rc = dlrm_copy_2d(m->g_send + o, (int64_t)cnt * D, m->dfeat + m->emb_col0 + (int64_t)first * D, m->feat_ld, B,
-                                      (int64_t)cnt * D, s))
-                return rc;
-        o += B * cnt * D;
-        first += cnt;
+    {
+        std::vector<dlrm_copy_item> items;
+        int64_t o = 0;
+        int first = 0;
+        for (int j = 0; j < m->world; j++) {
+            const int cnt = (int)m->tables_of_rank[j].size();
+            if (cnt)
+                items.push_back(dlrm_copy_item{m->g_send + o, (int64_t)cnt * D, m->dfeat + m->emb_col0 + (int64_t)first * D,
+                                               m->feat_ld, B, (int64_t)cnt * D});
+            o += B * cnt * D;
+            first += cnt;
+        }
+        if (int rc = dlrm_copy_2d_many(items.data(), (int32_t)items.size(), s)) return rc;
     }
     if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->g_send, m->recv_counts.data(), m->g_recv, m->send_counts.data(), s)) return rc;
     if (m->Tl)

@@ -375,6 +375,17 @@ def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None):
     return loss, dlogit
 
 
+def copy_2d_many_(pairs):
+    """dst[:, :] = src[:, :] for every (dst, src) pair of equally shaped row-major float32 views, one launch per 16 pairs."""
+    items = (_capi.CopyItem * len(pairs))()
+    for it, (dst, src) in zip(items, pairs):
+        _require_cuda(dst, src)
+        assert dst.shape == src.shape and dst.dtype == torch.float32 and src.dtype == torch.float32
+        it.d_dst, it.dst_ld, it.d_src, it.src_ld = dst.data_ptr(), _ld(dst), src.data_ptr(), _ld(src)
+        it.rows, it.cols = dst.shape
+    check(_capi.lib().dlrm_copy_2d_many(items, len(pairs), _stream()))
+
+
 @_op
 def copy_2d_(dst, src):
     """dst[:, :] = src[:, :] for two row-major 2-D float32 views (any row strides)."""

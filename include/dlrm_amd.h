@@ -81,6 +81,17 @@ int dlrm_table_init_uniform(void *dst, int row_dtype, int64_t n, uint64_t seed, 
  */
 int dlrm_copy_2d(float *d_dst, int64_t dst_ld, const float *d_src, int64_t src_ld, int64_t rows, int64_t cols,
                  dlrm_stream_t stream);
+/* Several such copies in one launch (the per-rank blocks of one exchange: a rank packs or unpacks the blocks of all
+ * its peers at once instead of one short launch per peer). */
+#define DLRM_COPY_MAX_ITEMS 16   /* per launch; longer lists take several launches */
+typedef struct dlrm_copy_item {
+    float *d_dst;
+    int64_t dst_ld;
+    const float *d_src;
+    int64_t src_ld;
+    int64_t rows, cols;
+} dlrm_copy_item;
+int dlrm_copy_2d_many(const dlrm_copy_item *items, int32_t n_items, dlrm_stream_t stream);
 
 /* ------------------------------------------------------------ EmbeddingBag */
 

@@ -166,6 +166,27 @@ def test_backward_weight_large_batch_split(oracle):
     assert rel_err(db.cpu().numpy(), db_ref) <= 1e-5
 
 
+def test_copy_2d_many():
+    """Several strided block copies in one launch (the per-peer blocks of an exchange): every block lands where the
+    one-at-a-time copy puts it, untouched elements stay untouched; aligned (16-byte) and unaligned shapes."""
+    from dlrm_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for cols_list, ld in (([128, 384, 256, 512, 128], 1408), ([3, 10, 1], 17)):
+        B = 37
+        src = [torch.randn((B, c), device="cuda", generator=g) for c in cols_list]
+        dst = torch.full((B, ld), -7.0, device="cuda")
+        ref = dst.clone()
+        pairs, c0 = [], 0
+        for x in src:
+            pairs.append((dst[:, c0:c0 + x.shape[1]], x))
+            ref[:, c0:c0 + x.shape[1]] = x
+            c0 += x.shape[1]
+        pairs = pairs * 4 if len(cols_list) == 3 else pairs       # more than 16 items: several launches
+        ops.copy_2d_many_(pairs)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, ref)
+
+
 def test_sgd_step(oracle):
     from dlrm_amd import ops
     rng = np.random.default_rng(4)
