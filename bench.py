@@ -394,25 +394,27 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         del scratch
 
     # forward only (inference), same batches
-    n_inf = max(min(args.steps, 10), 1)
-    for i in range(2):
-        model.forward(batches[i % n_batches][1], batches[i % n_batches][2])
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(n_inf):
-        dense, idx, off, labels, _ = batches[i % n_batches]
-        model.load_batch(dense, labels)
-        model.forward(idx, off)
-    torch.cuda.synchronize()
-    barrier()
-    dt_inf = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_inf = float(tt.item())
-    infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
-             "launch": "dlrm_model_forward"}
+    infer = None
+    if not args.no_inference:
+        n_inf = max(min(args.steps, 10), 1)
+        for i in range(2):
+            model.forward(batches[i % n_batches][1], batches[i % n_batches][2])
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_inf):
+            dense, idx, off, labels, _ = batches[i % n_batches]
+            model.load_batch(dense, labels)
+            model.forward(idx, off)
+        torch.cuda.synchronize()
+        barrier()
+        dt_inf = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_inf], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_inf = float(tt.item())
+        infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
+                 "launch": "dlrm_model_forward"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -458,6 +460,8 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--row-cap", type=int, default=0, help="cap rows per table (debug on small boxes); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true",
+                    help="skip the forward-only batches after the train steps (profiler passes that average per launch)")
     ap.add_argument("--sharding", default="table", choices=["table", "hybrid"],
                     help="N>1: whole tables per rank, or the biggest tables split by rows over all ranks")
     ap.add_argument("--row-wise-min-rows", type=int, default=20_000_000)

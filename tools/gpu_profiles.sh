@@ -49,9 +49,10 @@ for w in $WHAT; do
       ;;
     bench)
       trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline
-      pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-      pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-      # (bench.py also runs inference batches under the counters: per-launch averages only)
+      pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference
+      pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference
+      # (bench.py also launches operators outside the train steps -- the EmbeddingBag kernel on its own when the
+      # step reads the rows inside the interaction kernel: per-launch averages only)
       python3 $ROOT/tools/traffic_from_pmc.py "$OUT/bench_FETCH_SIZE_pmc.json" "$OUT/bench_WRITE_SIZE_pmc.json" 0 \
         "$OUT/hbm_traffic.json" mlperf:65536
       ;;
