@@ -352,24 +352,25 @@ def interact_dot_forward_gather(weight, indices, offsets, batch, num_tables, tab
 
 
 @_op
-def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None):
+def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None, want_loss=True, want_grad=True):
+    """want_loss / want_grad = False: that output is not computed (None is returned in its place)."""
     _require_cuda(pred, target)
     n = pred.numel()
     assert pred.is_contiguous() and target.is_contiguous() and target.numel() == n
-    loss = torch.empty(1, dtype=torch.float32, device=pred.device) if loss is None else loss
-    dpred = torch.empty_like(pred) if dpred is None else dpred
+    loss = (torch.empty(1, dtype=torch.float32, device=pred.device) if loss is None else loss) if want_loss else None
+    dpred = (torch.empty_like(pred) if dpred is None else dpred) if want_grad else None
     _emit("loss_mse", _ptr(pred), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss), _ptr(dpred),
           C.c_int32(int(relu_mask_pred)))
     return loss, dpred
 
 
 @_op
-def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None):
+def loss_bce_logits(logit, target, loss=None, dlogit=None, mean_over=None, want_loss=True, want_grad=True):
     _require_cuda(logit, target)
     n = logit.numel()
     assert logit.is_contiguous() and target.is_contiguous() and target.numel() == n
-    loss = torch.empty(1, dtype=torch.float32, device=logit.device) if loss is None else loss
-    dlogit = torch.empty_like(logit) if dlogit is None else dlogit
+    loss = (torch.empty(1, dtype=torch.float32, device=logit.device) if loss is None else loss) if want_loss else None
+    dlogit = (torch.empty_like(logit) if dlogit is None else dlogit) if want_grad else None
     _emit("loss_bce_logits", _ptr(logit), _ptr(target), C.c_int64(n), C.c_int64(mean_over or n), _ptr(loss),
           _ptr(dlogit))
     return loss, dlogit

@@ -301,3 +301,11 @@ def test_losses(oracle, n):
     l, d = ops.loss_bce_logits(torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda())
     assert abs(l.item() - l_ref) <= 1e-5 * abs(l_ref)
     assert rel_err(d.cpu().numpy(), d_ref) <= 1e-5
+    # either output on its own (a host asks for the value on a side stream): the same numbers bit for bit
+    l1, none = ops.loss_bce_logits(torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda(), want_grad=False)
+    none2, d1 = ops.loss_bce_logits(torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda(), want_loss=False)
+    assert none is None and none2 is None and torch.equal(l1, l) and torch.equal(d1, d)
+    lm, dmm = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True)
+    lm1, _ = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True, want_grad=False)
+    _, dm1 = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True, want_loss=False)
+    assert torch.equal(lm1, lm) and torch.equal(dm1, dmm)
