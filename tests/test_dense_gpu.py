@@ -227,7 +227,8 @@ def test_interact_dot(oracle, B, F, D):
 
 
 @pytest.mark.parametrize("B,T,D,idx_dtype", [(300, 26, 128, torch.int32), (2048, 26, 16, torch.int32), (77, 3, 64, torch.int64),
-                                             (4100, 7, 32, torch.int32), (65, 31, 8, torch.int32)])
+                                             (4100, 7, 32, torch.int32), (65, 31, 8, torch.int32),
+                                             (131105, 2, 8, torch.int32)])    # more chunks of 32 samples than workgroups
 def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtype):
     """One id per bag: the interaction forward that reads the rows straight from the tables gives, bit for bit, what
     EmbeddingBag forward + the interaction on its output give (same arithmetic on the same values), and its optional
