@@ -172,6 +172,17 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
     }
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
+        // the mask pieces of this row block are requested before the block is parked, so that they travel while the
+        // accumulators go through LDS (one round trip to memory per block instead of one per group of rows)
+        float4 mk[32 / RPI];
+        const bool mask_vec = p.mask != nullptr && c_vec && cn + 3 < p.N;
+        if (mask_vec) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int m = m0 + wr * (32 * MI) + mi * 32 + it * RPI + (lane / LPR);
+                mk[it] = *reinterpret_cast<const float4 *>(p.mask + (int64_t)(m < p.M ? m : p.M - 1) * p.mask_ld + cn);
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
@@ -179,7 +190,7 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
                 ct[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are done
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 32 / RPI; it++) {
             const int row = it * RPI + (lane / LPR);
             const int m = m0 + wr * (32 * MI) + mi * 32 + row;
@@ -189,8 +200,8 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
             if (m >= p.M || cn >= p.N) continue;
             float *dst = C + (int64_t)m * p.ldc + cn;
             if (c_vec && cn + 3 < p.N) {
-                if (p.mask) {
-                    const float4 k = *reinterpret_cast<const float4 *>(p.mask + (int64_t)m * p.mask_ld + cn);
+                if (mask_vec) {
+                    const float4 k = mk[it];
                     v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
                     v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
                 }
