@@ -270,6 +270,8 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     gemm_mode = ops.get_gemm_mode()
     gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
     cm, owner = None, None
+    if world == 1 and args.force_exchange:
+        cm = dcomm.Comm(dcomm.unique_id(), 0, 1)
     if world > 1:
         # (--share-gpu: ranks share a device, which RCCL refuses: dlrm_comm's rehearsal transport carries the calls)
         ids = [(dcomm.unique_id_rehearsal() if args.share_gpu else dcomm.unique_id()) if rank == 0 else None]
@@ -280,11 +282,11 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
             owner = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows).owner
     # one id per bag (Criteo's one-hot features): a single-GPU model reads the rows inside the interaction's forward kernel
     gather = (world == 1 and cfg.lookups == 1 and cfg.interaction == "dot" and cfg.row_dtype != "bf16" and
-              not args.no_gather)
+              not args.no_gather and not args.force_exchange)
     model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
                    overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
                    wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
-                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather)
+                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather, force_exchange=args.force_exchange)
     model.init_dense(0)
     Tl = model.info.num_whole_tables
     Trw = model.info.num_local_tables - Tl
@@ -434,7 +436,8 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
                        "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)",
                        "embedding_lookup": "inside the interaction's forward kernel (one id per bag)" if gather else
                        "EmbeddingBag kernel into a [B, T, D] block",
-                       "parallelism": "single GPU" if world == 1 else
+                       "parallelism": ("single GPU, sharded schedule with one peer" if args.force_exchange else "single GPU")
+                       if world == 1 else
                        ("%s x%d + data-parallel MLP" % ("table-wise" if not Trw else
                                                         "table-wise + %d row-wise tables" % Trw, world))},
             "loss": loss_value, "cache": None, "inference": infer, "roofline": roofline,
@@ -482,6 +485,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1, C host: run the sharded schedule (every exchange, with one peer, over RCCL) to price what "
+                         "the schedule itself costs beside the link time of a real multi-GPU run")
     ap.add_argument("--no-gather", action="store_true",
                     help="single GPU, one id per bag: pool the rows with the EmbeddingBag kernel into a [B, T, D] block "
                          "instead of reading them inside the interaction kernels")

@@ -81,6 +81,10 @@ class LinearBwdDesc(C.Structure):
     ]
 
 
+class FeatureView(C.Structure):
+    _fields_ = [("d_base", C.c_void_p), ("stride", C.c_int64)]
+
+
 class CopyItem(C.Structure):
     _fields_ = [
         ("d_dst", C.c_void_p), ("dst_ld", C.c_int64),

@@ -201,6 +201,7 @@ __device__ inline void bwd_sample(float *__restrict__ sx, const float *__restric
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    if (gx == nullptr) return;     // the caller sends the staged gradient where it belongs
 #pragma unroll
     for (int u = 0; u < NV; u++) {
         const int idx = u < NV - 1 ? lane + 64 * u : last_idx;
@@ -409,6 +410,136 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_gather_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Both kernels on features that do not sit in one [B, F, D] block: feature f of sample b is D floats at
+// base[f] + b * stride[f].  A sharded rank receives the pooled vectors as one block per source rank and sends the
+// gradients back the same way; with views the interaction reads and writes those exchange buffers directly (no
+// unpack / pack pass over [B, T, D] in between).  The table of views travels as a kernel argument and is parked in
+// LDS; a lane recomputes the place of its vectors per use (vec_place: D is a power of two).
+struct Views {
+    float *base[kFP];
+    int64_t stride[kFP];
+};
+
+template <int NV>
+__device__ inline void views_fetch(float *const *__restrict__ sb, const int64_t *__restrict__ sst, int64_t b, int n4, int D, int ld,
+                                   int lane, f32x4 (&v)[NV]) {
+    const int lv = opaque(lane);
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const VecPlace p = vec_place(lv, u, n4, D, ld);
+        v[u] = *reinterpret_cast<const f32x4 *>(sb[p.f] + b * sst[p.f] + p.col);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_views_kernel(Views xv, int64_t B, int F, int D,
+                                                                              float *__restrict__ out, int64_t out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = D + 4;
+    float *sx = smem + (size_t)wave * kFP * ld;
+    float **sb = reinterpret_cast<float **>(smem + (size_t)kIntWaves * kFP * ld);
+    int64_t *sst = reinterpret_cast<int64_t *>(sb + kFP);
+    if (threadIdx.x < F) { sb[threadIdx.x] = xv.base[threadIdx.x]; sst[threadIdx.x] = xv.stride[threadIdx.x]; }
+    for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;   // rows F..31 stay zero
+    __syncthreads();
+    const int n4 = F * D / 4;
+    const int64_t stride = (int64_t)gridDim.x * kIntWaves;
+    int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
+    f32x4 pre[NV];
+    views_fetch<NV>(sb, sst, b < B ? b : 0, n4, D, ld, lane, pre);
+    for (; b < B; b += stride) {
+        gather_park<NV>(sx, n4, D, ld, lane, pre);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        views_fetch<NV>(sb, sst, b + stride < B ? b + stride : b, n4, D, ld, lane, pre);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_views_kernel(Views xv, Views dv, const float *__restrict__ dout,
+                                                                              int64_t dout_ld, int64_t B, int F, int D,
+                                                                              int relu_mask0) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = D + 4;
+    const int per_wave = F * ld + F * kSLd + 4;
+    float *sx = smem + (size_t)wave * per_wave;
+    float *ss = sx + F * ld;
+    float **sb = reinterpret_cast<float **>(smem + (size_t)kIntWaves * per_wave);
+    int64_t *sst = reinterpret_cast<int64_t *>(sb + kFP);
+    float **db = reinterpret_cast<float **>(sst + kFP);
+    int64_t *dst = reinterpret_cast<int64_t *>(db + kFP);
+    if (threadIdx.x < F) {
+        sb[threadIdx.x] = xv.base[threadIdx.x]; sst[threadIdx.x] = xv.stride[threadIdx.x];
+        db[threadIdx.x] = dv.base[threadIdx.x]; dst[threadIdx.x] = dv.stride[threadIdx.x];
+    }
+    for (int i = lane; i < F * kSLd + 4; i += 64) ss[i] = 0.f;
+    __syncthreads();
+    const int n_pairs = F * (F - 1) / 2;
+    const int n4 = F * D / 4;
+    constexpr int kMaxPairs = (kFP * (kFP - 1) / 2 + 63) / 64;   // 8
+    int pij[kMaxPairs];   // (i << 8) | j of this lane's pair gradients, -1 past the last pair
+#pragma unroll
+    for (int u = 0; u < kMaxPairs; u++) {
+        const int c = lane + 64 * u;
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)c)) * 0.5f);
+        while (i * (i - 1) / 2 > c) i--;
+        while ((i + 1) * i / 2 <= c) i++;
+        pij[u] = c < n_pairs ? (i << 8) | (c - i * (i - 1) / 2) : -1;
+    }
+    const int last_idx = min(lane + 64 * (NV - 1), n4 - 1);
+    const int64_t stride = (int64_t)gridDim.x * kIntWaves;
+    int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
+    f32x4 pre[NV];
+    float pg[kMaxPairs];
+    auto fetch_grad = [&](int64_t bb) {
+        const float *go = dout + bb * dout_ld + D;
+#pragma unroll
+        for (int u = 0; u < kMaxPairs; u++) pg[u] = go[pij[u] >= 0 ? lane + 64 * u : 0];
+    };
+    views_fetch<NV>(sb, sst, b < B ? b : 0, n4, D, ld, lane, pre);
+    fetch_grad(b < B ? b : 0);
+    for (; b < B; b += stride) {
+        gather_park<NV>(sx, n4, D, ld, lane, pre);
+#pragma unroll
+        for (int u = 0; u < kMaxPairs; u++) {
+            const bool real = pij[u] >= 0;
+            const int i = pij[u] >> 8, jj = pij[u] & 255;
+            const float gv = real ? pg[u] : 0.f;
+            ss[real ? i * kSLd + jj : F * kSLd] = gv;     // lanes past the last pair write the spare cell
+            ss[real ? jj * kSLd + i : F * kSLd] = gv;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int64_t nb = b + stride < B ? b + stride : b;
+            views_fetch<NV>(sb, sst, nb, n4, D, ld, lane, pre);
+            fetch_grad(nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            int lds_off[NV];   // (unused by a bwd_sample that leaves the store to its caller)
+#pragma unroll
+            for (int u = 0; u < NV; u++) lds_off[u] = 0;
+            bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane);
+        }
+        {   // every feature's gradient to its own place
+            const int lv = opaque(lane);
+#pragma unroll
+            for (int u = 0; u < NV; u++) {
+                const VecPlace p = vec_place(lv, u, n4, D, ld);
+                *reinterpret_cast<f32x4 *>(db[p.f] + b * dst[p.f] + p.col) = *reinterpret_cast<const f32x4 *>(sx + p.lds);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace dlrm
 
 using namespace dlrm;
@@ -535,6 +666,79 @@ extern "C" int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const floa
         default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
     }
 #undef DLRM_INT_FWDG
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+static int check_views(const dlrm_feature_view *v, int32_t F, int32_t D, const char *what, Views *out) {
+    DLRM_REQUIRE(v != nullptr, "%s views are NULL", what);
+    for (int f = 0; f < F; f++) {
+        DLRM_REQUIRE(v[f].d_base != nullptr && reinterpret_cast<uintptr_t>(v[f].d_base) % 16 == 0 && v[f].stride % 4 == 0 &&
+                     v[f].stride >= D, "%s view %d: base must be 16-byte aligned, stride a multiple of 4 floats >= dim", what, f);
+        out->base[f] = v[f].d_base;
+        out->stride[f] = v[f].stride;
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_interact_dot_forward_views(const dlrm_feature_view *x_views, int64_t B, int32_t F, int32_t D, float *d_out,
+                                               int64_t out_ld, dlrm_stream_t stream) {
+    DLRM_REQUIRE(B >= 0 && F >= 1 && F <= kFP && D >= 8 && (D & (D - 1)) == 0 && F * D <= 4096,
+                 "views need 1 <= F <= %d, dim a power of two >= 8, F*dim <= 4096; got F=%d dim=%d", kFP, F, D);
+    if (B == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_out != nullptr && out_ld >= D + F * (F - 1) / 2, "out is NULL or out_ld too small");
+    Views xv{};
+    if (int rc = check_views(x_views, F, D, "x", &xv)) return rc;
+    const size_t lds = sizeof(float) * kIntWaves * kFP * (D + 4) + 16 * kFP;
+    const int64_t want = ceil_div(B, kIntWaves);
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    const int nv = (F * D / 4 + 63) / 64;
+#define DLRM_INT_FWDV(NV)                                                                                              \
+    case NV:                                                                                                           \
+        DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_views_kernel<NV>),                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        hipLaunchKernelGGL(interact_dot_fwd_views_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), \
+                           xv, B, F, D, d_out, out_ld);                                                                \
+        break;
+    switch (nv) {
+        DLRM_INT_FWDV(1) DLRM_INT_FWDV(2) DLRM_INT_FWDV(3) DLRM_INT_FWDV(4) DLRM_INT_FWDV(5) DLRM_INT_FWDV(6) DLRM_INT_FWDV(7)
+        DLRM_INT_FWDV(8) DLRM_INT_FWDV(9) DLRM_INT_FWDV(10) DLRM_INT_FWDV(11) DLRM_INT_FWDV(12) DLRM_INT_FWDV(13)
+        DLRM_INT_FWDV(14) DLRM_INT_FWDV(15) DLRM_INT_FWDV(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_FWDV
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_interact_dot_backward_views(const dlrm_feature_view *x_views, const float *d_dout, int64_t dout_ld, int64_t B,
+                                                int32_t F, int32_t D, const dlrm_feature_view *dx_views,
+                                                int32_t relu_mask_feature0, dlrm_stream_t stream) {
+    DLRM_REQUIRE(B >= 0 && F >= 1 && F <= kFP && D >= 8 && (D & (D - 1)) == 0 && F * D <= 4096,
+                 "views need 1 <= F <= %d, dim a power of two >= 8, F*dim <= 4096; got F=%d dim=%d", kFP, F, D);
+    if (B == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_dout != nullptr && dout_ld >= D + F * (F - 1) / 2, "dout is NULL or dout_ld too small");
+    Views xv{}, dv{};
+    if (int rc = check_views(x_views, F, D, "x", &xv)) return rc;
+    if (int rc = check_views(dx_views, F, D, "dx", &dv)) return rc;
+    const size_t lds = sizeof(float) * kIntWaves * ((size_t)F * (D + 4) + F * kSLd + 4) + 32 * kFP;
+    const int64_t want = ceil_div(B, kIntWaves);
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    const int nv = (F * D / 4 + 63) / 64;
+#define DLRM_INT_BWDV(NV)                                                                                              \
+    case NV:                                                                                                           \
+        DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_views_kernel<NV>),                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        hipLaunchKernelGGL(interact_dot_bwd_views_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), \
+                           xv, dv, d_dout, dout_ld, B, F, D, relu_mask_feature0);                                      \
+        break;
+    switch (nv) {
+        DLRM_INT_BWDV(1) DLRM_INT_BWDV(2) DLRM_INT_BWDV(3) DLRM_INT_BWDV(4) DLRM_INT_BWDV(5) DLRM_INT_BWDV(6) DLRM_INT_BWDV(7)
+        DLRM_INT_BWDV(8) DLRM_INT_BWDV(9) DLRM_INT_BWDV(10) DLRM_INT_BWDV(11) DLRM_INT_BWDV(12) DLRM_INT_BWDV(13)
+        DLRM_INT_BWDV(14) DLRM_INT_BWDV(15) DLRM_INT_BWDV(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_BWDV
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

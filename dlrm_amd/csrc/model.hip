@@ -52,6 +52,8 @@ struct dlrm_model {
     int64_t Bg;
     bool sharded, dot;
     bool gather = false;     // one id per bag: the interaction kernels read the rows themselves
+    bool views = false;      // sharded: the interaction reads / writes the exchange buffers in place (no unpack / pack)
+    std::vector<dlrm_feature_view> x_views, dx_views;
     // placement
     std::vector<int> my_tables, rw_tables, feature_order;
     std::vector<std::vector<int>> tables_of_rank;
@@ -217,8 +219,9 @@ static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t 
     }
     if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->a2a_send, m->send_counts.data(), m->a2a_recv, m->recv_counts.data(), s))
         return rc;
-    // the block of every source rank into its columns of the feature block, one launch
-    {
+    // the block of every source rank into its columns of the feature block, one launch (not needed when the
+    // interaction reads the blocks where they arrived)
+    if (!m->views) {
         std::vector<dlrm_copy_item> items;
         int64_t o = 0;
         int first = 0;
@@ -237,9 +240,10 @@ static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t 
         if (int rc = timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->rw_part, (int64_t)m->Trw * D, s); }))
             return rc;
         if (int rc = dlrm_comm_reduce_scatter_sum(m->cfg.comm, m->rw_part, m->rw_local, B * m->Trw * D, s)) return rc;
-        if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, m->rw_local, (int64_t)m->Trw * D, B,
-                                  (int64_t)m->Trw * D, s))
-            return rc;
+        if (!m->views)
+            if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, m->rw_local, (int64_t)m->Trw * D, B,
+                                      (int64_t)m->Trw * D, s))
+                return rc;
     }
     return DLRM_OK;
 }
@@ -269,7 +273,7 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
     if (m->cfg.presort && m->s_prep)
         if (int rc = wait_for(m, s, m->s_prep)) return rc;
     if (!m->sharded) return sparse_update(m, false, idx, off, n_idx, m->dfeat + m->emb_col0, m->feat_ld, s);
-    {
+    if (!m->views) {
         std::vector<dlrm_copy_item> items;
         int64_t o = 0;
         int first = 0;
@@ -287,9 +291,10 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
     if (m->Tl)
         if (int rc = sparse_update(m, false, idx, off, n_idx, m->g_recv, (int64_t)m->Tl * D, s)) return rc;
     if (m->Trw) {
-        if (int rc = dlrm_copy_2d(m->rw_local, (int64_t)m->Trw * D, m->dfeat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, B,
-                                  (int64_t)m->Trw * D, s))
-            return rc;
+        if (!m->views)
+            if (int rc = dlrm_copy_2d(m->rw_local, (int64_t)m->Trw * D, m->dfeat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, B,
+                                      (int64_t)m->Trw * D, s))
+                return rc;
         if (int rc = dlrm_comm_all_gather(m->cfg.comm, m->rw_local, m->rw_part, B * m->Trw * D, s)) return rc;
         if (int rc = sparse_update(m, true, idx, off, n_idx, m->rw_part, (int64_t)m->Trw * D, s)) return rc;
     }
@@ -337,8 +342,11 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
     } else {
         if (int rc = wait_for(m, main, emb)) return rc;
         if (m->dot)
-            if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main,
-                               [&] { return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main); }))
+            if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
+                    if (m->views)
+                        return dlrm_interact_dot_forward_views(m->x_views.data(), m->B, m->F, m->D, m->inter, m->inter_ld, main);
+                    return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main);
+                }))
                 return rc;
     }
     x = m->inter; xl = m->inter_ld;
@@ -568,6 +576,26 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
             if ((rc = dalloc(m, &m->rw_local, (size_t)((int64_t)m->B * m->Trw * D)))) return fail(rc);
         }
     }
+    if (sharded && m->dot && (m->D & (m->D - 1)) == 0 && m->D >= 8 && m->F <= 32 && m->F * m->D <= 4096 && !getenv("DLRM_NO_VIEWS")) {
+        // feature f of the interaction, where the exchanges leave it / where its gradient has to go
+        m->views = true;
+        const int64_t D = m->D;
+        m->x_views.push_back(dlrm_feature_view{m->feat, m->feat_ld});
+        m->dx_views.push_back(dlrm_feature_view{m->dfeat, m->feat_ld});
+        int64_t o = 0;
+        for (int j = 0; j < m->world; j++) {
+            const int64_t cnt = (int64_t)m->tables_of_rank[j].size();
+            for (int64_t k = 0; k < cnt; k++) {
+                m->x_views.push_back(dlrm_feature_view{m->a2a_recv + o + k * D, cnt * D});
+                m->dx_views.push_back(dlrm_feature_view{m->g_send + o + k * D, cnt * D});
+            }
+            o += (int64_t)m->B * cnt * D;
+        }
+        for (int64_t k = 0; k < m->Trw; k++) {      // row-wise tables: pooled sums in, gradients out, the same buffer
+            m->x_views.push_back(dlrm_feature_view{m->rw_local + k * D, (int64_t)m->Trw * D});
+            m->dx_views.push_back(dlrm_feature_view{m->rw_local + k * D, (int64_t)m->Trw * D});
+        }
+    }
     if (hipDeviceSynchronize() != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "model initialisation failed"));
     *out = m;
     return DLRM_OK;
@@ -724,6 +752,9 @@ extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const
         if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, m->dinter, m->inter_ld, main))
             return rc;
         if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_BACKWARD, main, [&] {
+                if (m->views)   // gradients straight into the send blocks of the backward exchange
+                    return dlrm_interact_dot_backward_views(m->x_views.data(), m->dinter, m->inter_ld, m->B, m->F, m->D,
+                                                            m->dx_views.data(), 1, main);
                 return dlrm_interact_dot_backward(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, main);
             }))
             return rc;

@@ -351,6 +351,38 @@ def interact_dot_forward_gather(weight, indices, offsets, batch, num_tables, tab
     return out
 
 
+def _views(ts, D):
+    v = (_capi.FeatureView * len(ts))()
+    for it, t in zip(v, ts):
+        _require_cuda(t)
+        assert t.dim() == 2 and t.shape[1] == D and t.stride(1) == 1 and t.dtype == torch.float32
+        it.d_base, it.stride = t.data_ptr(), t.stride(0)
+    return v
+
+
+def interact_dot_forward_views(xs, out=None, out_ld=None):
+    """interact_dot_forward on features given one by one: xs[f] is a [B, D] row-major view (any row stride)."""
+    B, D = xs[0].shape
+    F = len(xs)
+    n_out = D + F * (F - 1) // 2
+    if out is None:
+        out_ld = n_out if out_ld is None else out_ld
+        out = torch.empty((B, out_ld), dtype=torch.float32, device=xs[0].device)
+    check(_capi.lib().dlrm_interact_dot_forward_views(_views(xs, D), C.c_int64(B), C.c_int32(F), C.c_int32(D), _ptr(out),
+                                                      C.c_int64(out_ld), _stream()))
+    return out
+
+
+def interact_dot_backward_views(xs, dout, dxs, relu_mask_feature0=False):
+    """interact_dot_backward likewise: the gradient of feature f is written to the [B, D] view dxs[f]."""
+    B, D = xs[0].shape
+    F = len(xs)
+    _require_cuda(dout)
+    check(_capi.lib().dlrm_interact_dot_backward_views(_views(xs, D), _ptr(dout), C.c_int64(_ld(dout)), C.c_int64(B), C.c_int32(F),
+                                                       C.c_int32(D), _views(dxs, D), C.c_int32(int(relu_mask_feature0)), _stream()))
+    return dxs
+
+
 @_op
 def loss_mse(pred, target, relu_mask_pred=False, loss=None, dpred=None, mean_over=None, want_loss=True, want_grad=True):
     """want_loss / want_grad = False: that output is not computed (None is returned in its place)."""

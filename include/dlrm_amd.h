@@ -313,6 +313,26 @@ int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const float *d_x0, in
                                      float *d_x_copy, dlrm_stream_t stream);
 
 /*
+ * The dot interaction on features that do not sit in one [B, F, dim] block: feature f of sample b is dim floats at
+ * views[f].d_base + b * views[f].stride (floats).  A sharded rank receives the pooled vectors as one block per source
+ * rank and returns their gradients the same way: with views the interaction reads / writes those exchange buffers
+ * in place and the unpack / pack passes between exchange and interaction disappear (the reference is one process and
+ * has no counterpart; its concat is src/dlrmtest.cpp:265).  Same arithmetic and results as dlrm_interact_dot_forward /
+ * _backward on the assembled block.  dim must be a power of two >= 8, F <= 32, every base 16-byte aligned, every
+ * stride a multiple of 4 floats; the view arrays are host arrays of F entries.  _backward writes the gradient of
+ * feature f at dx_views[f] (a sample's gradients may go back to where its features were read from).
+ */
+typedef struct dlrm_feature_view {
+    float *d_base;
+    int64_t stride;
+} dlrm_feature_view;
+int dlrm_interact_dot_forward_views(const dlrm_feature_view *x_views, int64_t B, int32_t F, int32_t D, float *d_out,
+                                    int64_t out_ld, dlrm_stream_t stream);
+int dlrm_interact_dot_backward_views(const dlrm_feature_view *x_views, const float *d_dout, int64_t dout_ld, int64_t B,
+                                     int32_t F, int32_t D, const dlrm_feature_view *dx_views, int32_t relu_mask_feature0,
+                                     dlrm_stream_t stream);
+
+/*
  * Loss forward + backward in one pass, mean reduction over n predictions.
  *   mse : torch::mse_loss (src/dlrmtest.cpp:522);  d_dpred = 2 (pred - target) / n
  *   bce : binary cross entropy with logits (MLPerf DLRM loss; not in the

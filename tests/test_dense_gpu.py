@@ -166,6 +166,46 @@ def test_backward_weight_large_batch_split(oracle):
     assert rel_err(db.cpu().numpy(), db_ref) <= 1e-5
 
 
+@pytest.mark.parametrize("B,F,D", [(300, 27, 128), (2048, 27, 16), (77, 4, 64), (9, 32, 8)])
+def test_interact_dot_views_equal_the_dense_block(B, F, D):
+    """Features scattered over several buffers (the per-peer blocks of an exchange, different row strides): the
+    interaction over views gives what the kernels give on the assembled [B, F, D] block, bit for bit, forward and
+    backward -- also when the gradients are written over the features they were computed from."""
+    from dlrm_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B + F + D)
+    x = torch.randn((B, F, D), device="cuda", generator=g)
+    x[:, 0, :].clamp_(min=0)
+    n_out = D + F * (F - 1) // 2
+    out_ld = (n_out + 3) // 4 * 4
+    dout = torch.randn((B, out_ld), device="cuda", generator=g)
+    ref_out = ops.interact_dot_forward(x, out_ld=out_ld)
+    ref_dx = ops.interact_dot_backward(x, dout, relu_mask_feature0=True)
+    # feature 0 in a wide buffer of its own, the others in blocks of 1, 2, 3, ... features with their own strides
+    blocks, f = [], 1
+    wide = torch.zeros((B, F * D + 8), device="cuda")
+    wide[:, :D] = x[:, 0, :]
+    xs = [wide[:, :D]]
+    n = 1
+    while f < F:
+        cnt = min(n, F - f)
+        blk = x[:, f:f + cnt, :].reshape(B, cnt * D).contiguous()
+        blocks.append(blk)
+        xs += [blk[:, i * D:(i + 1) * D] for i in range(cnt)]
+        f += cnt
+        n += 1
+    out = ops.interact_dot_forward_views(xs, out_ld=out_ld)
+    dxs = [torch.empty_like(t) for t in xs]
+    ops.interact_dot_backward_views(xs, dout, dxs, relu_mask_feature0=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    for i in range(F):
+        assert torch.equal(dxs[i], ref_dx[:, i, :]), i
+    ops.interact_dot_backward_views(xs, dout, xs, relu_mask_feature0=True)      # in place
+    torch.cuda.synchronize()
+    for i in range(F):
+        assert torch.equal(xs[i], ref_dx[:, i, :]), i
+
+
 def test_copy_2d_many():
     """Several strided block copies in one launch (the per-peer blocks of an exchange): every block lands where the
     one-at-a-time copy puts it, untouched elements stay untouched; aligned (16-byte) and unaligned shapes."""
