@@ -286,7 +286,10 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
                    overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
                    wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
-                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather, force_exchange=args.force_exchange)
+                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather, force_exchange=args.force_exchange,
+                   graph_steps=args.graph and world == 1)
+    if args.graph:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))    # a graph cannot be captured on the NULL stream
     model.init_dense(0)
     Tl = model.info.num_whole_tables
     Trw = model.info.num_local_tables - Tl
@@ -331,7 +334,10 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     probe = model.collect_timing()
     timed_cls = [k for k, _ in sorted(probe.items(), key=lambda kv: -kv[1][0]) if k != "embbag_backward_prepare"][:1] \
         or ["linear_backward_data"]
-    model.enable_timing(timed_cls, 16 * args.steps)
+    model.enable_timing([] if args.graph else timed_cls, 16 * args.steps)
+    if args.graph:
+        for i in range(n_batches):      # capture every resident batch before the timed region
+            step(args.warmup + i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -368,6 +374,9 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     for k in kernels:
         k["traffic"] = traffic.get(k["op"]) if traffic else None
     model.enable_timing([], 0)
+    if roofline is None and kernels:     # (--graph: nothing is bracketed inside a replayed graph)
+        roofline = roofline_of(kernels[0], gemm_mode, traffic)
+        roofline["timed"] = "HIP events around this operator's launches in %d directly launched steps after the timed region" % n_k
     emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
     emb_note = "EmbeddingBag forward launches inside the step"
     if emb is None and gather:
@@ -433,7 +442,8 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
                        "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
                        if gemm_mode == 1 else "float32 MFMA",
-                       "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)",
+                       "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)" +
+                       ("; captured into a HIP graph per resident batch and replayed" if args.graph and world == 1 else ""),
                        "embedding_lookup": "inside the interaction's forward kernel (one id per bag)" if gather else
                        "EmbeddingBag kernel into a [B, T, D] block",
                        "parallelism": ("single GPU, sharded schedule with one peer" if args.force_exchange else "single GPU")
@@ -485,6 +495,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: collectives backend (gloo only to rehearse the sharded step where ranks share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses device r %% device_count")
+    ap.add_argument("--graph", action="store_true",
+                    help="C host, N = 1: the step is captured into a HIP graph per resident batch and replayed "
+                         "(dlrm_model_config.graph_steps); the operator classes are then timed only after the timed region")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1, C host: run the sharded schedule (every exchange, with one peer, over RCCL) to price what "
                          "the schedule itself costs beside the link time of a real multi-GPU run")

@@ -24,7 +24,7 @@ class ModelConfig(C.Structure):
         ("local_batch", C.c_int64), ("rank", C.c_int32), ("world", C.c_int32), ("comm", C.c_void_p),
         ("table_owner", C.POINTER(C.c_int32)), ("force_exchange", C.c_int32),
         ("overlap", C.c_int32), ("presort", C.c_int32), ("wgrad_stream", C.c_int32),
-        ("seed", C.c_uint64), ("init_tables", C.c_int32), ("one_id_per_bag", C.c_int32),
+        ("seed", C.c_uint64), ("init_tables", C.c_int32), ("one_id_per_bag", C.c_int32), ("graph_steps", C.c_int32),
     ]
 
 
@@ -55,7 +55,7 @@ class CModel:
 
     def __init__(self, cfg, batch, rank=0, world=1, comm=None, table_owner=None, seed=0, force_exchange=False,
                  overlap=-1, presort=1, wgrad_stream=-1, idx_dtype=torch.int32, device="cuda", gemm_mode=0,
-                 one_id_per_bag=False):
+                 one_id_per_bag=False, graph_steps=False):
         self.L = _capi.lib()
         self.cfg, self.B, self.rank, self.world = cfg, batch, rank, world
         self.dev = torch.device(device)
@@ -83,6 +83,7 @@ class CModel:
         c.force_exchange, c.overlap, c.presort, c.wgrad_stream = int(force_exchange), overlap, presort, wgrad_stream
         c.seed, c.init_tables = seed, 1
         c.one_id_per_bag = int(one_id_per_bag)
+        c.graph_steps = int(graph_steps)
         self.h = C.c_void_p()
         check(self.L.dlrm_model_create(C.byref(c), C.byref(self.h)))
         info = ModelInfo()

@@ -87,6 +87,10 @@ struct dlrm_model {
     std::vector<TimeRec> trecs;
     size_t n_trecs = 0;
     uint32_t time_mask = 0;
+    // captured steps (cfg.graph_steps): one instantiated graph per set of batch buffers
+    struct Captured { const void *idx, *off; int64_t n; hipStream_t stream; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
+    std::vector<Captured> graphs;
+    uint64_t graph_clock = 0;
 };
 
 namespace dlrm {
@@ -382,6 +386,7 @@ extern "C" int dlrm_model_destroy(dlrm_model *m) {
     if (!m) return DLRM_OK;
     (void)hipDeviceSynchronize();
     for (void *p : m->allocs) (void)hipFree(p);
+    for (auto &g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
     for (auto &r : m->trecs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (m->s_emb) (void)hipStreamDestroy(m->s_emb);
@@ -725,14 +730,56 @@ extern "C" int dlrm_model_forward(dlrm_model *m, const void *d_indices, const vo
     return forward_pass(m, d_indices, d_offsets, n_indices, false, as_stream(stream));
 }
 
+static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices, hipStream_t main);
+
+// cfg.graph_steps: the step's launches, stream forks and joins are captured once per set of batch buffers (a host
+// that cycles a few resident buffers, or double-buffers its input) and replayed with one hipGraphLaunch.  At small
+// batches a step is ~60 launches of 3-20 us on four streams and the time between them is what the step consists of.
+static int graphed_step(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices, hipStream_t main) {
+    constexpr size_t kMaxGraphs = 8;
+    m->graph_clock++;
+    for (auto &g : m->graphs)
+        if (g.idx == d_indices && g.off == d_offsets && g.n == n_indices && g.stream == main) {
+            g.used = m->graph_clock;
+            DLRM_HIP(hipGraphLaunch(g.exec, main));
+            return DLRM_OK;
+        }
+    if (m->graphs.size() >= kMaxGraphs) {      // forget the set that was used longest ago
+        size_t old = 0;
+        for (size_t i = 1; i < m->graphs.size(); i++)
+            if (m->graphs[i].used < m->graphs[old].used) old = i;
+        DLRM_HIP(hipStreamSynchronize(m->graphs[old].stream));
+        (void)hipGraphExecDestroy(m->graphs[old].exec);
+        (void)hipGraphDestroy(m->graphs[old].graph);
+        m->graphs.erase(m->graphs.begin() + old);
+    }
+    dlrm_model::Captured g{d_indices, d_offsets, n_indices, main, nullptr, nullptr, m->graph_clock};
+    DLRM_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
+    const int rc = train_step_impl(m, d_indices, d_offsets, n_indices, main);
+    const hipError_t e = hipStreamEndCapture(main, &g.graph);
+    if (rc) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+    DLRM_HIP(e);
+    DLRM_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    m->graphs.push_back(g);
+    DLRM_HIP(hipGraphLaunch(g.exec, main));
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices,
                                      dlrm_stream_t stream) {
     DLRM_REQUIRE(m != nullptr, "model is NULL");
     DLRM_REQUIRE((d_indices != nullptr || n_indices == 0) && d_offsets != nullptr && n_indices >= 0, "bad batch");
     hipStream_t main = as_stream(stream);
+    if (int rc = ensure_sparse_ws(m, d_indices, d_offsets, n_indices)) return rc;
+    // (a step that brackets operators with timing events, and the exchanges of a sharded step, are launched directly)
+    if (m->cfg.graph_steps && !m->sharded && m->time_mask == 0 && main != nullptr)
+        return graphed_step(m, d_indices, d_offsets, n_indices, main);
+    return train_step_impl(m, d_indices, d_offsets, n_indices, main);
+}
+
+static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices, hipStream_t main) {
     hipStream_t emb = m->s_emb ? m->s_emb : main;
     const dlrm_model_config &c = m->cfg;
-    if (int rc = ensure_sparse_ws(m, d_indices, d_offsets, n_indices)) return rc;
     if (int rc = forward_pass(m, d_indices, d_offsets, n_indices, true, main)) return rc;
     // loss (means over the GLOBAL batch, so the ranks' gradients add): the gradient on the critical path, the
     // value -- one workgroup's fixed-order sum, which nothing downstream reads -- beside the backward pass

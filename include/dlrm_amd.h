@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1011
+#define DLRM_ABI_VERSION 1012
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -748,6 +748,11 @@ typedef struct dlrm_model_config {
                                  /* inside the interaction's forward kernel (dlrm_interact_dot_forward_gather) instead */
                                  /* of pooling them into a [B, T, dim] block first; a batch that breaks the promise raises */
                                  /* *d_error_flag (2) and its offending bags count as zero rows */
+    int32_t graph_steps;         /* 1: dlrm_model_train_step captures its launches, stream forks and joins into a HIP */
+                                 /* graph the first time it sees a set of batch buffers (d_indices, d_offsets, */
+                                 /* n_indices, stream) and replays the graph afterwards (the 8 most recent sets are */
+                                 /* kept): for hosts that cycle resident buffers.  The caller's stream must not be the */
+                                 /* NULL stream.  Sharded models and steps with operator timing launch directly. */
 } dlrm_model_config;
 
 typedef struct dlrm_model_info_t {
