@@ -20,7 +20,11 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void mfma_spin(float *out, int iters) {
     bf16x8 a, b;
-    for (int i = 0; i < 8; i++) { a[i] = (short)(0x3f80 + threadIdx.x + i); b[i] = (short)(0x3f00 + i); }
+    for (int i = 0; i < 8; i++) {   // operands with random signs and mantissas: constant inputs draw far less power
+        const unsigned h = (threadIdx.x * 8u + i + blockIdx.x * 2048u) * 2654435761u;
+        a[i] = (short)(((h >> 8) & 0x807f) | 0x3f80);
+        b[i] = (short)(((h >> 17) & 0x807f) | 0x3f00);
+    }
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
     for (int i = 0; i < iters; i++) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
@@ -31,6 +35,33 @@ __global__ __launch_bounds__(256) void mfma_spin(float *out, int iters) {
     float s = 0.f;
     for (int i = 0; i < 16; i++) s += acc0[i] + acc1[i] + acc2[i] + acc3[i];
     if (s == 12345.f) out[0] = s;
+}
+
+// VALU / LDS instruction loops that the GEMM kernels of this library are made of (besides the MFMAs above)
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_spin(float *out, int iters) {
+    __shared__ float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = (float)i;
+    __syncthreads();
+    float a = 1.0f + threadIdx.x, b = 0.5f + blockIdx.x;
+    f32x2 p = {a, b}, q = {b, a};
+    unsigned r = 0;
+    f32x2 t = {0.f, 0.f};
+    const unsigned addr = (threadIdx.x * 8u) & 0x3ff8u;
+    for (int i = 0; i < iters; i++) {
+        if constexpr (KIND == 1) {
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_cvt_pk_bf16_f32 %0, %2, %1\n\tv_cvt_pk_bf16_f32 %0, %1, %2\n\tv_cvt_pk_bf16_f32 %0, %2, %1"
+                         : "=&v"(r) : "v"(a), "v"(b));
+        } else if constexpr (KIND == 2) {
+            asm volatile("v_pk_add_f32 %0, %1, %2\n\tv_pk_add_f32 %0, %2, %1\n\tv_pk_add_f32 %0, %1, %2\n\tv_pk_add_f32 %0, %2, %1"
+                         : "=&v"(t) : "v"(p), "v"(q));
+        } else if constexpr (KIND == 3) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(addr) : "memory");
+        } else if constexpr (KIND == 4) {
+            asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=&v"(r) : "v"((unsigned)i), "v"(addr), "v"(r));
+        }
+    }
+    if (r == 0x12345u && t[0] == 3.25f) out[0] = a + lds[threadIdx.x];
 }
 
 __device__ inline float smul(float a, float b) {   // a product the compiler cannot pack
@@ -88,13 +119,19 @@ int main(int argc, char **argv) {
     hipStream_t sa, sb;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    const char *names[] = {"alone", "beside MFMA waves", "beside v_cvt_pk_bf16_f32 waves", "beside v_pk_add_f32 waves",
+                           "beside ds_read_b64_tr_b16 waves", "beside v_bitop3_b32 waves"};
     for (int mode = 0; mode < 2; mode++)
-        for (int with_mfma = 0; with_mfma < 2; with_mfma++) {
+        for (int with_mfma = 0; with_mfma < (mode == 0 ? 6 : 2); with_mfma++) {
             unsigned tot[2] = {0, 0};
             for (int r = 0; r < reps; r++) {
                 CK(hipMemsetAsync(bad, 0, 8, sa));
                 CK(hipStreamSynchronize(sa));
-                if (with_mfma) hipLaunchKernelGGL(mfma_spin, dim3(512), dim3(256), 0, sb, sink, 20000);
+                if (with_mfma == 1) hipLaunchKernelGGL(mfma_spin, dim3(512), dim3(256), 0, sb, sink, 20000);
+                if (with_mfma == 2) hipLaunchKernelGGL(valu_spin<1>, dim3(1024), dim3(256), 0, sb, sink, 40000);
+                if (with_mfma == 3) hipLaunchKernelGGL(valu_spin<2>, dim3(1024), dim3(256), 0, sb, sink, 40000);
+                if (with_mfma == 4) hipLaunchKernelGGL(valu_spin<3>, dim3(1024), dim3(256), 0, sb, sink, 40000);
+                if (with_mfma == 5) hipLaunchKernelGGL(valu_spin<4>, dim3(1024), dim3(256), 0, sb, sink, 100000);
                 if (mode == 0) hipLaunchKernelGGL(victim<0>, dim3(2048), dim3(256), 0, sa, g, n_vec, 200, bad);
                 else hipLaunchKernelGGL(victim<1>, dim3(2048), dim3(256), 0, sa, g, n_vec, 200, bad);
                 CK(hipDeviceSynchronize());
@@ -103,7 +140,7 @@ int main(int argc, char **argv) {
                 tot[0] += hb[0]; tot[1] += hb[1];
             }
             printf("%s, %s: wrong low halves %u, wrong high halves %u (of %.3g results per half)\n",
-                   mode == 0 ? "packed (v_pk_mul_f32 / v_pk_fma_f32)" : "scalar float32", with_mfma ? "beside MFMA waves" : "alone",
+                   mode == 0 ? "packed (v_pk_mul_f32 / v_pk_fma_f32)" : "scalar float32", names[with_mfma],
                    tot[0], tot[1], 2.0 * reps * 2048.0 * 256.0 * 200.0);
             fflush(stdout);
         }
