@@ -62,14 +62,18 @@ def test_sparse_update_beside_weight_gradients_equals_the_serial_run():
             assert torch.equal(dw, dwr) and torch.equal(db, dbr)
 
 
-def test_c_hosted_step_with_a_lagging_weight_gradient_stream_is_repeatable():
+@pytest.mark.parametrize("shape", ["kaggle", "mlperf_capped"])
+def test_c_hosted_step_with_a_lagging_weight_gradient_stream_is_repeatable(shape):
     """Timing events around every weight gradient hold that stream back until it overlaps the sparse update; tables,
     dense parameters and predictions of two steps must not depend on it."""
     from dlrm_amd.cmodel import CModel
     from dlrm_amd.data import synthetic_batch
     from dlrm_amd.model import DLRMConfig
-    cfg = DLRMConfig.kaggle()
-    B = 2048
+    if shape == "kaggle":
+        cfg, B = DLRMConfig.kaggle(), 2048
+    else:                                   # the MLPerf layers and row width at the local batch of an 8-GPU run
+        cfg, B = DLRMConfig.mlperf(), 8192
+        cfg.table_rows = [min(r, 200000) for r in cfg.table_rows]
     dev = torch.device("cuda", 0)
     batches = [synthetic_batch(cfg.table_rows, B, 1, cfg.dense_in, dev, seed=1000 + i, loss=cfg.loss, dist="uniform",
                                local_batch=B) for i in range(2)]
@@ -78,7 +82,7 @@ def test_c_hosted_step_with_a_lagging_weight_gradient_stream_is_repeatable():
         m = CModel(cfg, B, seed=0, one_id_per_bag=True)
         m.init_dense(0)
         if timed:
-            m.enable_timing(["linear_backward_weight"], 4000)
+            m.enable_timing(timed, 4000)
         for dense, idx, off, labels in batches:
             m.load_batch(dense.contiguous(), labels)
             m.train_step(idx, off)
@@ -87,8 +91,8 @@ def test_c_hosted_step_with_a_lagging_weight_gradient_stream_is_repeatable():
         m.close()
         return out
 
-    ref = run(False)
+    ref = run(None)
     for rep in range(4):
-        got = run(True)
+        got = run(["linear_backward_weight"] if rep % 2 == 0 else "all")
         for name, a, b in zip(("tables", "dense parameters", "predictions"), ref, got):
             assert torch.equal(a, b), "repetition %d: %s differ" % (rep, name)

@@ -176,7 +176,9 @@ def sparse_mlperf(B=65536, D=128):
     return out
 
 
-def interact(B=65536, F=27, D=128):
+def interact(B=None, F=27, D=128):
+    if B is None:
+        return [interact(b, F, D) for b in (int(v) for v in os.environ.get("INTERACT_B", "65536,8192").split(","))]
     x = torch.randn(B, F, D, device="cuda")
     n_out = D + F * (F - 1) // 2
     ld = pad4(n_out)
@@ -185,7 +187,7 @@ def interact(B=65536, F=27, D=128):
     dx = torch.empty_like(x)
     t_f = timeit(lambda: ops.interact_dot_forward(x, out=o, out_ld=ld))
     t_b = timeit(lambda: ops.interact_dot_backward(x, do[:, :n_out], relu_mask_feature0=True, out=dx))
-    rec = {"fwd_us": t_f * 1e6, "fwd_GBps": B * (F * D + n_out) * 4 / t_f / 1e9, "bwd_us": t_b * 1e6,
+    rec = {"B": B, "fwd_us": t_f * 1e6, "fwd_GBps": B * (F * D + n_out) * 4 / t_f / 1e9, "bwd_us": t_b * 1e6,
            "bwd_GBps": B * (2 * F * D + n_out) * 4 / t_b / 1e9}
     print(json.dumps(rec))
     return rec
