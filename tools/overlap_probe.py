@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--aggressor", default="wgrad")
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--launches", type=int, default=16)
+    ap.add_argument("--victim", default="update", choices=["update", "synthetic", "synthetic-scalar", "synthetic-waw"],
+                    help="synthetic: the bare load -> v_pk_mul_f32 / v_pk_fma_f32 pattern of tools/aggressors.hip, which checks itself")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -77,6 +79,30 @@ def main():
             assert rc == 0
 
 
+    if a.victim != "update":
+        if agg is None:
+            agg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libaggressors.so"))
+        vec = torch.randn(1 << 22, device=dev) * 1e-3
+        bad = torch.zeros(2, dtype=torch.int32, device=dev)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        bad_runs = 0
+        for rep in range(a.reps):
+            bad.zero_()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(sb):
+                for _ in range(a.launches if a.aggressor != "none" else 0):
+                    aggress()
+            with torch.cuda.stream(sa):
+                rc = agg.launch_victim({"synthetic": 0, "synthetic-scalar": 1, "synthetic-waw": 2}[a.victim], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                       ctypes.c_void_p(vec.data_ptr()), 1 << 20, 100, ctypes.c_void_p(bad.data_ptr()))
+                assert rc == 0
+            torch.cuda.synchronize()
+            lo, hi = bad.tolist()
+            bad_runs += (lo + hi) > 0
+            if lo + hi:
+                print("   repetition %d: %d wrong low halves, %d wrong high halves" % (rep, lo, hi))
+        print("victim %s, aggressor %-8s: %d of %d overlapped runs had wrong results" % (a.victim, a.aggressor, bad_runs, a.reps), flush=True)
+        return
     ref = w0.clone()
     apply(ref)
     torch.cuda.synchronize()
