@@ -38,6 +38,30 @@ BF16_MFMA_PEAK = 2.5e15   # FLOP/s, v_mfma_f32_32x32x16_bf16 dense peak
 # A float32 product evaluated as six bf16 MFMA terms (split of each operand into three bf16
 # pieces) can at best run at a sixth of the bf16 rate: that is the roofline of that kernel.
 BF16X3_PEAK = BF16_MFMA_PEAK / 6.0
+# ... and as three f16 MFMA terms (two f16 pieces per operand; the f16 pipe has the bf16 rate) at a third of it
+F16X2_PEAK = BF16_MFMA_PEAK / 3.0
+
+# evaluation of the big layers' float32 products: name -> (C ABI gemm_mode, kernel label, peak, MFMA terms, notes)
+GEMM_CHOICES = {
+    "f32": (1, "gemm_f32_kernel", F32_MFMA_PEAK, 1.0, "float32 MFMA dense peak", "float32 MFMA"),
+    "bf16x3": (2, "gemm_split_kernel<3 bf16 pieces>", BF16X3_PEAK, 6.0,
+               "float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6",
+               "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"),
+    "f16x2": (3, "gemm_split_kernel<2 f16 pieces>", F16X2_PEAK, 3.0,
+              "float32 product = 3 f16 MFMA terms: peak = 2500 TFLOP/s f16 dense / 3",
+              "float32 in/out; products as 3 f16 MFMA terms of 2-way f16 splits of the operands scaled by powers of two, "
+              "f32 accumulate (representation error about one float32 ulp per product)"),
+}
+
+
+def gemm_choice(args, local_batch):
+    """--gemm auto: f16 pieces for local batches of 8192 and above (what dlrm_model_* does for DLRM_GEMM_DEFAULT),
+    bf16 pieces below; DLRM_GEMM_MODE=0 / 2 in the environment force the float32 MFMA / the f16 pieces."""
+    from dlrm_amd import ops
+    name = args.gemm
+    if name == "auto":
+        name = {0: "f32", 2: "f16x2"}.get(ops.get_gemm_mode(), "f16x2" if local_batch >= 8192 else "bf16x3")
+    return name
 
 
 class KernelTimer:
@@ -148,9 +172,9 @@ def install_timers(ops, model_ref):
 
 
 KERNEL_OF = {
-    "linear_forward": "gemm_%s_kernel<RC,RC> (x W^T + b, ReLU)",
-    "linear_backward_data": "gemm_%s_kernel<RC,RS> (dz W, ReLU mask)",
-    "linear_backward_weight": "gemm_%s_kernel<RS,RS> split-batch + reduce_slabs + colsum (dz^T x)",
+    "linear_forward": "%s, operands RC,RC (x W^T + b, ReLU)",
+    "linear_backward_data": "%s, operands RC,RS (dz W, ReLU mask)",
+    "linear_backward_weight": "%s, operands RS,RS, split-batch + reduce_slabs + colsum (dz^T x)",
     "embbag_forward": "embbag_fwd_group_kernel",
     "embbag_backward_update": "sparse_update_kernel + combine_runs_kernel (segmented reduction + fused optimizer)",
     "embbag_backward_prepare": "expand_pairs + rocprim radix sort (ids only; overlapped with the forward pass)",
@@ -236,16 +260,15 @@ def kernel_rows(timing, work, steps, gemm_name, gemm_peak):
     return rows
 
 
-def roofline_of(dom, gemm_mode, traffic):
+def roofline_of(dom, gemm, traffic):
     r = {"kernel": dom["kernel"], "bound": dom["bound"],
          "achieved": dom["achieved"] * (1e3 if dom["bound"] == "hbm" else 1.0),
          "peak": dom["peak"] * (1e3 if dom["bound"] == "hbm" else 1.0),
          "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
          "avg_launch_ms": dom["avg_launch_ms"], "traffic": traffic.get(dom["op"]) if traffic else None}
     if dom["bound"] == "mfma":
-        r["peak_note"] = ("float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6"
-                          if gemm_mode == 1 else "float32 MFMA dense peak")
-        r["mfma_tflops_executed"] = dom["achieved"] * (6.0 if gemm_mode == 1 else 1.0)
+        r["peak_note"] = GEMM_CHOICES[gemm][4]
+        r["mfma_tflops_executed"] = dom["achieved"] * GEMM_CHOICES[gemm][3]
     return r
 
 
@@ -267,8 +290,8 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     from dlrm_amd import ops
     from dlrm_amd.cmodel import CModel
     from dlrm_amd.data import synthetic_batch
-    gemm_mode = ops.get_gemm_mode()
-    gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
+    gemm = gemm_choice(args, B)
+    gemm_name, gemm_peak = GEMM_CHOICES[gemm][1], GEMM_CHOICES[gemm][2]
     cm, owner = None, None
     if world == 1 and args.force_exchange:
         cm = dcomm.Comm(dcomm.unique_id(), 0, 1)
@@ -286,7 +309,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
                    overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
                    wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
-                   gemm_mode=2 if gemm_mode == 1 else 1, one_id_per_bag=gather, force_exchange=args.force_exchange,
+                   gemm_mode=GEMM_CHOICES[gemm][0], one_id_per_bag=gather, force_exchange=args.force_exchange,
                    graph_steps=args.graph and world == 1)
     if args.graph:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))    # a graph cannot be captured on the NULL stream
@@ -360,7 +383,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     timed_ids = [args.warmup + i for i in range(args.steps)]
     dom_rows = kernel_rows(model.collect_timing(), work_for(timed_ids), args.steps, gemm_name, gemm_peak)
     traffic = load_traffic(world, "%s:%d" % (args.config, Bg))
-    roofline = roofline_of(dom_rows[0], gemm_mode, traffic) if dom_rows else None
+    roofline = roofline_of(dom_rows[0], gemm, traffic) if dom_rows else None
     if roofline:
         roofline["timed"] = "HIP events around this operator's launches inside the timed steps"
 
@@ -375,7 +398,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         k["traffic"] = traffic.get(k["op"]) if traffic else None
     model.enable_timing([], 0)
     if roofline is None and kernels:     # (--graph: nothing is bracketed inside a replayed graph)
-        roofline = roofline_of(kernels[0], gemm_mode, traffic)
+        roofline = roofline_of(kernels[0], gemm, traffic)
         roofline["timed"] = "HIP events around this operator's launches in %d directly launched steps after the timed region" % n_k
     emb = next((k for k in kernels if k["op"] == "embbag_forward"), None)
     emb_note = "EmbeddingBag forward launches inside the step"
@@ -440,8 +463,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
                        "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
                        "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
-                       "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
-                       if gemm_mode == 1 else "float32 MFMA",
+                       "gemm": GEMM_CHOICES[gemm][5],
                        "launch": "step hosted in libdlrm_amd.so (dlrm_model_train_step); exchanges over dlrm_comm (RCCL)" +
                        ("; captured into a HIP graph per resident batch and replayed" if args.graph and world == 1 else ""),
                        "embedding_lookup": "inside the interaction's forward kernel (one id per bag)" if gather else
@@ -507,6 +529,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="embedding side on the caller's stream")
     ap.add_argument("--overlap", action="store_true", help="embedding side on its own stream (default for N>1)")
     ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")
+    ap.add_argument("--gemm", default="auto", choices=["auto", "f32", "bf16x3", "f16x2"],
+                    help="evaluation of the big layers' float32 products (auto: f16x2 from a local batch of 8192 up, else bf16x3)")
     ap.add_argument("--wgrad-stream", default="auto", choices=["auto", "on", "off"],
                     help="MLP weight gradients on their own stream beside the data gradients (auto: local batch <= 32768)")
     ap.add_argument("--progress", action="store_true", help="synchronise and print a line to stderr after every step")
@@ -561,8 +585,11 @@ def main():
         return run_c_host(args, cfg, Bg, B, rank, world, dev)
     model_ref = {"unique_rows": 0, "unique_rows_rw": 0, "lookups": cfg.lookups, "world": world}
     timer = install_timers(ops, model_ref)
-    gemm_mode = ops.get_gemm_mode()   # 1: float32 products as six bf16 MFMA terms; 0: float32 MFMA
-    gemm_name, gemm_peak = ("bf16x3", BF16X3_PEAK) if gemm_mode == 1 else ("f32", F32_MFMA_PEAK)
+    gemm = gemm_choice(args, B)
+    if gemm == "f16x2" and args.gemm == "auto" and ops.get_gemm_mode() != 2:
+        gemm = "bf16x3"     # (the Python-hosted operators would measure every operand in a pass of its own)
+    ops.set_gemm_mode({"f32": 0, "bf16x3": 1, "f16x2": 2}[gemm])
+    gemm_name, gemm_peak = GEMM_CHOICES[gemm][1], GEMM_CHOICES[gemm][2]
     plan = None
     if args.sharding == "hybrid" and world > 1:
         from dlrm_amd.sharding import plan_hybrid
@@ -688,9 +715,8 @@ def main():
                     "unit": "GB/s" if dom["bound"] == "hbm" else "TFLOP/s", "frac": dom["frac"],
                     "avg_launch_ms": dom["avg_launch_ms"], "traffic": None}
         if dom["bound"] == "mfma":
-            roofline["peak_note"] = ("float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6"
-                                     if gemm_mode == 1 else "float32 MFMA dense peak")
-            roofline["mfma_tflops_executed"] = dom["achieved"] * (6.0 if gemm_mode == 1 else 1.0)
+            roofline["peak_note"] = GEMM_CHOICES[gemm][4]
+            roofline["mfma_tflops_executed"] = dom["achieved"] * GEMM_CHOICES[gemm][3]
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         traffic = {} if cached else load_traffic(world, "%s:%d" % (args.config, Bg))
         if traffic:
@@ -753,8 +779,7 @@ def main():
                        "total_rows": sum(cfg.table_rows), "lookups_per_bag": cfg.lookups,
                        "bottom_mlp": [cfg.dense_in] + cfg.bottom, "top_mlp": [cfg.top_in] + cfg.top,
                        "interaction": cfg.interaction, "loss": cfg.loss, "emb_optimizer": cfg.emb_optimizer,
-                       "gemm": "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"
-                       if gemm_mode == 1 else "float32 MFMA",
+                       "gemm": GEMM_CHOICES[gemm][5],
                        "launch": "eager (one Python call per operator)" if args.eager else
                        "recorded step replayed through dlrm_plan_run",
                        "parallelism": "single GPU" if world == 1 else

@@ -15,14 +15,14 @@ POOL_SUM, POOL_MEAN = 0, 1
 DUP_ACCUMULATE, DUP_LAST_WINS = 0, 1
 OPT_SGD, OPT_ADAGRAD_ROWWISE = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
-GEMM_DEFAULT, GEMM_F32_MFMA, GEMM_BF16X3 = 0, 1, 2
+GEMM_DEFAULT, GEMM_F32_MFMA, GEMM_BF16X3, GEMM_F16X2 = 0, 1, 2, 3
 
 
 class DlrmError(RuntimeError):
     pass
 
 
-ABI_VERSION = 1012   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
+ABI_VERSION = 1013   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
 
 
 class EmbBagDesc(C.Structure):
@@ -64,6 +64,7 @@ class LinearDesc(C.Structure):
         ("d_y", C.c_void_p), ("y_ld", C.c_int64),
         ("act", C.c_int32),
         ("gemm_mode", C.c_int32),
+        ("d_x_absmax", C.c_void_p), ("d_w_absmax", C.c_void_p), ("d_y_absmax", C.c_void_p),
     ]
 
 
@@ -78,6 +79,7 @@ class LinearBwdDesc(C.Structure):
         ("d_dw", C.c_void_p), ("dw_ld", C.c_int64),
         ("d_db", C.c_void_p),
         ("gemm_mode", C.c_int32),
+        ("d_dz_absmax", C.c_void_p), ("d_w_absmax", C.c_void_p), ("d_x_absmax", C.c_void_p), ("d_dx_absmax", C.c_void_p),
     ]
 
 

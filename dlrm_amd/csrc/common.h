@@ -70,4 +70,30 @@ __device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &
     l = __builtin_bit_cast(unsigned, lb);
 }
 
+// Two-piece split on the f16 matrix pipe: xs = x * scale with scale a power of two that puts the operand's largest
+// magnitude just below 2^14 (so h cannot overflow f16), h = f16(xs), l = f16(xs - h).  h + l carries 22 mantissa bits of
+// every element within 2^11 of the largest and at least 2^-38 of the largest magnitude in absolute terms for the rest;
+// the three leading cross terms hh + hl + lh with float32 accumulation leave a representation error near one float32
+// ulp (measured 7.5e-8 relative rms against float64, below the accumulation error of any float32 GEMM).
+// a pair of float32 -> the pair's two f16 pieces (each packed in one dword), 8 VALU operations
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ inline void split2_pair(f32x2 x, float scale, unsigned &h, unsigned &l) {
+    const f32x2 xs = x * scale;
+    const f16x2 hh = __builtin_convertvector(xs, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const f32x2 r = xs - __builtin_convertvector(hh, f32x2);
+    const f16x2 lh = __builtin_convertvector(r, f16x2);
+    l = __builtin_bit_cast(unsigned, lh);
+}
+
+// power-of-two scale for an operand whose largest magnitude has the float32 bits `absmax_bits`: the scaled maximum
+// lands in [2^13, 2^14); zero / denormal maxima scale by 2^127, infinities and NaNs by 2^-115 (the product is then
+// whatever float32 arithmetic makes of them)
+__device__ inline float split2_scale(unsigned absmax_bits) {
+    const int e = (int)((absmax_bits >> 23) & 0xffu);
+    int se = 267 - e;
+    se = se > 254 ? 254 : (se < 1 ? 1 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
 }  // namespace dlrm

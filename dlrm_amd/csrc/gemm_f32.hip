@@ -30,6 +30,7 @@
 // both operands, so the pairing of reduction indices is consistent.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -64,6 +65,8 @@ struct GemmParams {
     int64_t slab_stride;  // elements between the partial outputs of consecutive splits
     float *colsum;        // RS A operand only: [splits][M] sums of A over this split's reduction range
                           // (the bias gradient of the weight-gradient product), or NULL
+    const float *a_max, *b_max;   // f16x2 evaluation: device scalars holding max |A|, max |B| (float32 bit patterns)
+    float *c_max;         // or NULL: max |C| over everything this launch stores is folded in with atomicMax
 };
 
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
@@ -163,6 +166,7 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
     const int cn = n0 + wc * (32 * NI) + (lane % LPR) * 4;
     const bool c_vec = (reinterpret_cast<uintptr_t>(C) % 16 == 0) && (p.ldc % 4 == 0) &&
                        (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
+    float vmax = 0.f;     // largest magnitude this lane stores (for c_max)
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) {
         if (cn < p.N) bv.x = p.bias[cn];
@@ -206,6 +210,7 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
                     v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4 *>(dst) = v;
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             } else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -214,11 +219,19 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
                         float x = e[q];
                         if (p.mask) x = p.mask[(int64_t)m * p.mask_ld + cn + q] > 0.f ? x : 0.f;
                         dst[q] = x;
+                        vmax = fmaxf(vmax, fabsf(x));
                     }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+    if (p.c_max != nullptr) {     // (non-negative floats order like their bit patterns; a NaN counts as huge)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
+        // (only if it can still raise the slot: see absmax_kernel)
+        if (lane == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned *>(p.c_max))
+            atomicMax(reinterpret_cast<unsigned *>(p.c_max), __float_as_uint(vmax));
     }
 }
 
@@ -477,9 +490,10 @@ __device__ inline void load_half_scalar(const TileAddr<RC, R> &t, int r0, int r_
     }
 }
 
-// split the registers of one half-step and write the pieces to the three planes at `planes`
-template <bool RC, int R>
-__device__ inline void split_store_half(unsigned char *__restrict__ planes, const f32x4 *xs) {
+// split the registers of one half-step and write the pieces to the NP planes at `planes` (NP = 3: bf16 pieces,
+// NP = 2: f16 pieces of the values times `scale`)
+template <bool RC, int R, int NP>
+__device__ inline void split_store_half(unsigned char *__restrict__ planes, const f32x4 *xs, float scale) {
     const int tid = threadIdx.x;
     constexpr int LPR = R / 4;
 #pragma unroll
@@ -488,12 +502,20 @@ __device__ inline void split_store_half(unsigned char *__restrict__ planes, cons
         int off;
         if constexpr (RC) off = rc_chunk_off((tid >> 2) + 64 * v, (tid & 3) >> 1) + 8 * (tid & 1);
         else off = rs_chunk_off<R>(tid / LPR + (256 / LPR) * v, (tid % LPR) >> 1) + 8 * (tid & 1);
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pair(f32x2{x[0], x[1]}, h0, m0, l0);
-        split3_pair(f32x2{x[2], x[3]}, h1, m1, l1);
-        *reinterpret_cast<u32x2 *>(planes + off) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2 *>(planes + plane_bytes(R) + off) = u32x2{m0, m1};
-        *reinterpret_cast<u32x2 *>(planes + 2 * plane_bytes(R) + off) = u32x2{l0, l1};
+        if constexpr (NP == 3) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3_pair(f32x2{x[0], x[1]}, h0, m0, l0);
+            split3_pair(f32x2{x[2], x[3]}, h1, m1, l1);
+            *reinterpret_cast<u32x2 *>(planes + off) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(planes + plane_bytes(R) + off) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2 *>(planes + 2 * plane_bytes(R) + off) = u32x2{l0, l1};
+        } else {
+            unsigned h0, l0, h1, l1;
+            split2_pair(f32x2{x[0], x[1]}, scale, h0, l0);
+            split2_pair(f32x2{x[2], x[3]}, scale, h1, l1);
+            *reinterpret_cast<u32x2 *>(planes + off) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(planes + plane_bytes(R) + off) = u32x2{l0, l1};
+        }
     }
 }
 
@@ -528,29 +550,36 @@ __device__ inline bf16x8 load_frag16(const unsigned char *__restrict__ plane, in
 __device__ inline void pin_here(f32x4 &a) { asm volatile("" : "+v"(a)); }
 
 // the fragments of one 16-deep half-step of the wave's output block, out of one stage
-template <int MI, int NI>
+template <int MI, int NI, int NP>
 struct Frags {
-    bf16x8 a[MI][3], b[NI][3];
+    bf16x8 a[MI][NP], b[NI][NP];   // (raw 16-bit pieces: bf16 for NP = 3, f16 for NP = 2)
 };
 
-// piece of A and piece of B that meet in cross term t, in the order mfma_frags issues the terms
-constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0};
-constexpr int kTermB[6] = {0, 1, 2, 0, 1, 0};
+// piece of A and piece of B that meet in cross term t, in the order mfma_frags issues the terms (smallest first):
+// three bf16 pieces -> six terms, two f16 pieces -> three terms
+constexpr int kTermA3[6] = {2, 1, 0, 1, 0, 0};
+constexpr int kTermB3[6] = {0, 1, 2, 0, 1, 0};
+constexpr int kTermA2[3] = {1, 0, 0};
+constexpr int kTermB2[3] = {0, 1, 0};
+template <int NP> constexpr int n_terms() { return NP == 3 ? 6 : 3; }
+template <int NP> constexpr int term_a(int t) { return NP == 3 ? kTermA3[t] : kTermA2[t]; }
+template <int NP> constexpr int term_b(int t) { return NP == 3 ? kTermB3[t] : kTermB2[t]; }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // The reads are issued in the order the MFMAs first need them: the first MFMA waits for two fragments, not for
 // all of them (LDS reads return in order, so the wait before a use covers every read issued ahead of it).
-template <bool A_RC, bool B_RC, int TM, int TN>
-__device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags<TM / 64, TN / 64> &f) {
+template <bool A_RC, bool B_RC, int TM, int TN, int NP>
+__device__ inline void load_frags(const unsigned char *__restrict__ stage, int wr, int wc, Frags<TM / 64, TN / 64, NP> &f) {
     constexpr int MI = TM / 64, NI = TN / 64;
-    const unsigned char *pa = stage, *pb = stage + 3 * plane_bytes(TM);
-    bool have_a[MI][3] = {}, have_b[NI][3] = {};
+    const unsigned char *pa = stage, *pb = stage + NP * plane_bytes(TM);
+    bool have_a[MI][NP] = {}, have_b[NI][NP] = {};
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const int x = kTermA[t], y = kTermB[t];
+            for (int t = 0; t < n_terms<NP>(); t++) {
+                const int x = term_a<NP>(t), y = term_b<NP>(t);
                 if (!have_a[mi][x]) {
                     f.a[mi][x] = load_frag16<A_RC, TM>(pa + x * plane_bytes(TM), wr * (TM / 2) + mi * 32);
                     have_a[mi][x] = true;
@@ -562,17 +591,22 @@ __device__ inline void load_frags(const unsigned char *__restrict__ stage, int w
             }
 }
 
-// six cross terms for each of the wave's 32x32 accumulators, smallest terms first
-template <int MI, int NI>
-__device__ inline void mfma_frags(const Frags<MI, NI> &f, f32x16 (&acc)[MI][NI]) {
+// the cross terms for each of the wave's 32x32 accumulators, smallest terms first
+template <int MI, int NI, int NP>
+__device__ inline void mfma_frags(const Frags<MI, NI, NP> &f, f32x16 (&acc)[MI][NI]) {
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
             f32x16 c = acc[mi][ni];
 #pragma unroll
-            for (int t = 0; t < 6; t++)
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][kTermA[t]], f.b[ni][kTermB[t]], c, 0, 0, 0);
+            for (int t = 0; t < n_terms<NP>(); t++) {
+                if constexpr (NP == 3)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][term_a<NP>(t)], f.b[ni][term_b<NP>(t)], c, 0, 0, 0);
+                else
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[mi][term_a<NP>(t)]),
+                                                               __builtin_bit_cast(f16x8, f.b[ni][term_b<NP>(t)]), c, 0, 0, 0);
+            }
             acc[mi][ni] = c;
         }
 }
@@ -581,30 +615,36 @@ __device__ inline void mfma_frags(const Frags<MI, NI> &f, f32x16 (&acc)[MI][NI])
 // 4 (MI+NI) elements per lane -- 18 vector operations per piece -- and its LDS writes): all reads first, then
 // the split operations spread evenly behind the MFMAs, the writes of an operand once its pieces are complete.
 // (128 x 128: three split operations behind every MFMA.)
-template <int I, int MI, int NI>
+template <int I, int MI, int NI, int NP>
 __device__ inline void interleave_from() {
-    constexpr int kMfma = 6 * MI * NI, kValu = 18 * (MI + NI), kWrites = (3 * (MI + NI)) / 4;
+    constexpr int kMfma = n_terms<NP>() * MI * NI, kValu = (NP == 3 ? 18 : 16) * (MI + NI), kWrites = (NP * (MI + NI)) / 4;
     if constexpr (I < kMfma) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, (kValu * (I + 1)) / kMfma - (kValu * I) / kMfma, 0);
         if constexpr (I == kMfma / 2 - 1 || I == kMfma - 1) __builtin_amdgcn_sched_group_barrier(0x200, kWrites, 0);
-        interleave_from<I + 1, MI, NI>();
+        interleave_from<I + 1, MI, NI, NP>();
     }
 }
 
-template <int MI, int NI>
+template <int MI, int NI, int NP>
 __device__ inline void interleave_half() {
-    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + NI), 0);
-    interleave_from<0, MI, NI>();
+    __builtin_amdgcn_sched_group_barrier(0x100, NP * (MI + NI), 0);
+    interleave_from<0, MI, NI, NP>();
 }
 
-template <bool A_RC, bool B_RC, int TM, int TN>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams p) {
+template <bool A_RC, bool B_RC, int TM, int TN, int NP>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams p) {
     constexpr int MI = TM / 64, NI = TN / 64, PA = TM / 64, PB = TN / 64;
-    constexpr int kStage = 3 * plane_bytes(TM) + 3 * plane_bytes(TN);   // A planes then B planes
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage];
-    static_assert(2 * kStage >= 4 * 32 * (32 * NI + 4) * 4, "the output staging must fit the operand stages");
+    constexpr int kStage = NP * plane_bytes(TM) + NP * plane_bytes(TN);   // A planes then B planes
+    constexpr int kOutStaging = 4 * 32 * (32 * NI + 4) * 4;               // the epilogue parks accumulators here
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage > kOutStaging ? 2 * kStage : kOutStaging];
     unsigned char *const s0 = smem, *const s1 = smem + kStage;
+    // f16 pieces: power-of-two scales from the operands' largest magnitudes (wave-uniform scalars)
+    float scale_a = 1.f, scale_b = 1.f;
+    if constexpr (NP == 2) {
+        scale_a = split2_scale(__float_as_uint(*p.a_max));
+        scale_b = split2_scale(__float_as_uint(*p.b_max));
+    }
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -646,8 +686,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
                 cs += live ? add : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        split_store_half<A_RC, TM>(stage, &xa[h * PA]);
-        split_store_half<B_RC, TN>(stage + 3 * plane_bytes(TM), &xb[h * PB]);
+        split_store_half<A_RC, TM, NP>(stage, &xa[h * PA], scale_a);
+        split_store_half<B_RC, TN, NP>(stage + NP * plane_bytes(TM), &xb[h * PB], scale_b);
     };
 
     // Tiles [t_begin, t_end) of the reduction through the two-stage pipeline.  VEC: 16-byte loads
@@ -687,28 +727,28 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
         // tile tt and (va, vb) half 0 of tile tt+1 (in flight or landed).  Every half-step requests the
         // half tile that is staged two half-steps later, into the registers staged one half-step ago.
         auto tile_step = [&](int tt, f32x4 (&ua)[2 * PA], f32x4 (&ub)[2 * PB], f32x4 (&va)[2 * PA], f32x4 (&vb)[2 * PB]) {
-            Frags<MI, NI> f;
+            Frags<MI, NI, NP> f;
             load(tt + 1, 1, va, vb);
             __builtin_amdgcn_sched_barrier(0);   // the requests go out ahead of the MFMA block
-            load_frags<A_RC, B_RC, TM, TN>(s0, wr, wc, f);   // reads first: the writes below go to the other stage
+            load_frags<A_RC, B_RC, TM, TN, NP>(s0, wr, wc, f);   // reads first: the writes below go to the other stage
             pin(ua, ub, 1);
             if constexpr (MASK) { mask_tail(&ua[PA], PA, k_begin + tt * BK, 1); mask_tail(&ub[PB], PB, k_begin + tt * BK, 1); }
             stage_half(s1, ua, ub, 1, true);
-            mfma_frags<MI, NI>(f, acc);
-            interleave_half<MI, NI>();
+            mfma_frags<MI, NI, NP>(f, acc);
+            interleave_half<MI, NI, NP>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             load(tt + 2, 0, ua, ub);
             __builtin_amdgcn_sched_barrier(0);
-            load_frags<A_RC, B_RC, TM, TN>(s1, wr, wc, f);
+            load_frags<A_RC, B_RC, TM, TN, NP>(s1, wr, wc, f);
             pin(va, vb, 0);
             if constexpr (MASK) {
                 const int tn = tt + 1 < t_end ? tt + 1 : t_end - 1;
                 mask_tail(&va[0], PA, k_begin + tn * BK, 0); mask_tail(&vb[0], PB, k_begin + tn * BK, 0);
             }
             stage_half(s0, va, vb, 0, tt + 1 < t_end);
-            mfma_frags<MI, NI>(f, acc);
-            interleave_half<MI, NI>();
+            mfma_frags<MI, NI, NP>(f, acc);
+            interleave_half<MI, NI, NP>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         };
@@ -740,6 +780,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16x3_kernel(GemmParams
     }
     if (t_done < steps) run(std::false_type{}, std::false_type{}, t_done, steps);   // edge tiles, unaligned operands
 
+    if constexpr (NP == 2) {      // undo the operand scales (two exact multiplications: either factor alone stays in range)
+        const float inv_a = 1.0f / scale_a, inv_b = 1.0f / scale_b;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = (acc[mi][ni][r] * inv_a) * inv_b;
+    }
     float *fsm = reinterpret_cast<float *>(smem);
     if constexpr (!A_RC) {
         if (do_colsum) {
@@ -860,24 +909,117 @@ static TileShape pick_tile(int64_t M, int64_t N, int64_t red, int *splits_out) {
 }
 
 template <bool A_RC, bool B_RC, int TM, int TN>
-static void launch_bf16x3(const GemmParams &p, unsigned nwg, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<A_RC, B_RC, TM, TN>), dim3(nwg), dim3(kGemmThreads), 0, s, p);
+static void launch_split(const GemmParams &p, int pieces, unsigned nwg, hipStream_t s) {
+    if (pieces == 3) hipLaunchKernelGGL((gemm_split_kernel<A_RC, B_RC, TM, TN, 3>), dim3(nwg), dim3(kGemmThreads), 0, s, p);
+    else hipLaunchKernelGGL((gemm_split_kernel<A_RC, B_RC, TM, TN, 2>), dim3(nwg), dim3(kGemmThreads), 0, s, p);
+}
+
+// ---- largest magnitude of an operand (f16x2 evaluation): one pass over a [rows, cols] matrix, folded into *slot with
+// atomicMax on the bit patterns (non-negative floats order like unsigned integers; the slot must start at 0)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t rows, int cols, int64_t ld, int vec,
+                                                      int lanes_per_row, unsigned *__restrict__ slot) {
+    // lanes_per_row (a power of two, at most 64) lanes share a row; a wave takes 64 / lanes_per_row rows at a time
+    const int lane = threadIdx.x & 63;
+    const int lr = lane / lanes_per_row, lc = lane % lanes_per_row;
+    const int rows_per_wave = 64 / lanes_per_row;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int cols4 = vec ? cols / 4 : 0;     // 16-byte pieces per row (rows start on 16-byte boundaries)
+    unsigned m = 0;
+    for (int64_t r = wave * rows_per_wave + lr; r < rows; r += n_waves * rows_per_wave) {
+        const float *row = x + r * ld;
+        for (int c = lc; c < cols4; c += lanes_per_row) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);
+            const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+            const unsigned c2 = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+            m = max(max(m, max(a, b)), max(c2, d));
+        }
+        for (int c = 4 * cols4 + lc; c < cols; c += lanes_per_row) m = max(m, __float_as_uint(row[c]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, k, 64));
+    // one atomic per workgroup, and only if it can still raise the slot (thousands of atomics on one address would
+    // queue up behind each other; a stale read here costs one atomic too many, never a wrong result)
+    __shared__ unsigned part[4];
+    if (lane == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, m);
+    }
+}
+
+static int launch_absmax(const float *x, int64_t rows, int cols, int64_t ld, float *slot, hipStream_t s) {
+    const int vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ld % 4 == 0;
+    const int per_row = vec ? (cols + 3) / 4 : cols;
+    int lanes = 1;
+    while (lanes < 64 && lanes < per_row) lanes <<= 1;
+    const int64_t waves = ceil_div(rows, 64 / lanes);
+    int64_t blocks = ceil_div(waves, 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, cols, ld, vec, lanes,
+                       reinterpret_cast<unsigned *>(slot));
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+// Slots for callers that bring no operand maxima: a ring inside the loaded code object (no allocation at launch).
+// A launch takes the next pair; the ring is long enough that a pair is not handed out again while a launch that was
+// given it can still be in flight on any stream of an ordinary host (a captured graph keeps the pairs it was
+// captured with: hosts that replay graphs beside direct launches pass their own slots in the descriptors).
+constexpr unsigned kMaxRing = 8192;
+static __device__ unsigned g_max_ring[2 * kMaxRing];
+static void *g_max_ring_ptr[64];
+static std::atomic<unsigned> g_max_ring_next{0};
+
+static int ring_pair(float **out) {
+    int dev = -1;
+    DLRM_HIP(hipGetDevice(&dev));
+    DLRM_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d outside 0..63", dev);
+    if (g_max_ring_ptr[dev] == nullptr) {
+        void *q = nullptr;
+        DLRM_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(g_max_ring)));
+        DLRM_REQUIRE(q != nullptr, "hipGetSymbolAddress returned NULL");
+        g_max_ring_ptr[dev] = q;
+    }
+    *out = static_cast<float *>(g_max_ring_ptr[dev]) + 2 * (g_max_ring_next.fetch_add(1) % kMaxRing);
+    return DLRM_OK;
+}
+
+// fills p.a_max / p.b_max for the f16x2 evaluation: the caller's slots, or a pass over the operand into ring slots
+static int operand_maxima(GemmParams &p, const float *given_a, int64_t rows_a, int cols_a, const float *given_b, int64_t rows_b,
+                          int cols_b, hipStream_t s) {
+    p.a_max = given_a; p.b_max = given_b;
+    if (given_a && given_b) return DLRM_OK;
+    float *pair = nullptr;
+    if (int rc = ring_pair(&pair)) return rc;
+    DLRM_HIP(hipMemsetAsync(pair, 0, 2 * sizeof(float), s));
+    if (!given_a) {
+        if (int rc = launch_absmax(p.A, rows_a, cols_a, p.lda, pair, s)) return rc;
+        p.a_max = pair;
+    }
+    if (!given_b) {
+        if (int rc = launch_absmax(p.B, rows_b, cols_b, p.ldb, pair + 1, s)) return rc;
+        p.b_max = pair + 1;
+    }
+    return DLRM_OK;
 }
 
 template <bool A_RC, bool B_RC>
 static int launch_gemm(GemmParams p, int splits, TileShape ts, int mode, hipStream_t s) {
-    DLRM_REQUIRE(mode == DLRM_GEMM_DEFAULT || mode == DLRM_GEMM_F32_MFMA || mode == DLRM_GEMM_BF16X3,
-                 "gemm_mode must be DLRM_GEMM_DEFAULT, _F32_MFMA or _BF16X3, got %d", mode);
+    DLRM_REQUIRE(mode == DLRM_GEMM_DEFAULT || mode == DLRM_GEMM_F32_MFMA || mode == DLRM_GEMM_BF16X3 || mode == DLRM_GEMM_F16X2,
+                 "gemm_mode must be DLRM_GEMM_DEFAULT, _F32_MFMA, _BF16X3 or _F16X2, got %d", mode);
+    const int pieces = mode == DLRM_GEMM_F16X2 ? 2 : 3;
+    DLRM_REQUIRE(pieces == 3 || (p.a_max != nullptr && p.b_max != nullptr), "f16x2 evaluation without operand maxima");
     if (mode == DLRM_GEMM_F32_MFMA) ts = TileShape{BM, BN};    // the float32-MFMA kernel has the one tile
     p.gx = (int)ceil_div(p.N, ts.tn); p.gy = (int)ceil_div(p.M, ts.tm); p.gz = splits;
     const int64_t nwg = (int64_t)p.gx * p.gy * p.gz;
     DLRM_REQUIRE(nwg < (1ll << 31), "GEMM grid too large");
     if (mode == DLRM_GEMM_F32_MFMA)
         hipLaunchKernelGGL((gemm_f32_kernel<A_RC, B_RC>), dim3((unsigned)nwg), dim3(kGemmThreads), 0, s, p);
-    else if (ts.tm == 128 && ts.tn == 128) launch_bf16x3<A_RC, B_RC, 128, 128>(p, (unsigned)nwg, s);
-    else if (ts.tm == 128) launch_bf16x3<A_RC, B_RC, 128, 64>(p, (unsigned)nwg, s);
-    else if (ts.tn == 128) launch_bf16x3<A_RC, B_RC, 64, 128>(p, (unsigned)nwg, s);
-    else launch_bf16x3<A_RC, B_RC, 64, 64>(p, (unsigned)nwg, s);
+    else if (ts.tm == 128 && ts.tn == 128) launch_split<A_RC, B_RC, 128, 128>(p, pieces, (unsigned)nwg, s);
+    else if (ts.tm == 128) launch_split<A_RC, B_RC, 128, 64>(p, pieces, (unsigned)nwg, s);
+    else if (ts.tn == 128) launch_split<A_RC, B_RC, 64, 128>(p, pieces, (unsigned)nwg, s);
+    else launch_split<A_RC, B_RC, 64, 64>(p, pieces, (unsigned)nwg, s);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -899,6 +1041,13 @@ static TileShape wgrad_shape(int64_t M, int N, int K, int mode, int *splits) {
 
 using namespace dlrm;
 
+extern "C" int dlrm_absmax(const float *d_x, int64_t rows, int32_t cols, int64_t ld, float *d_slot, dlrm_stream_t stream) {
+    DLRM_REQUIRE(rows >= 0 && cols >= 1 && ld >= cols && d_slot != nullptr, "bad arguments");
+    if (rows == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_x != nullptr, "NULL operand");
+    return launch_absmax(d_x, rows, cols, ld, d_slot, as_stream(stream));
+}
+
 extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     DLRM_REQUIRE(l != nullptr, "linear descriptor is NULL");
     DLRM_REQUIRE(l->M >= 0 && l->N >= 1 && l->K >= 1, "bad shape M=%lld N=%d K=%d", (long long)l->M, l->N, l->K);
@@ -918,6 +1067,9 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->K, BK) * BK;
+    p.c_max = l->d_y_absmax;
+    if (l->gemm_mode == DLRM_GEMM_F16X2)
+        if (int rc = operand_maxima(p, l->d_x_absmax, l->M, l->K, l->d_w_absmax, l->N, l->K, as_stream(stream))) return rc;
     return launch_gemm<true, true>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
@@ -938,6 +1090,9 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     p.mask = l->d_relu_mask; p.mask_ld = l->relu_mask_ld;
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->N, BK) * BK;
+    p.c_max = l->d_dx_absmax;
+    if (l->gemm_mode == DLRM_GEMM_F16X2)    // (B = W [N,K]: rows are reduction indices)
+        if (int rc = operand_maxima(p, l->d_dz_absmax, l->M, l->N, l->d_w_absmax, l->N, l->K, as_stream(stream))) return rc;
     return launch_gemm<true, false>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
@@ -994,6 +1149,8 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
     p.M = l->N; p.N = l->K; p.K = (int)l->M;  // C = dW [N,K], reduction over the batch
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(ceil_div(l->M, splits), BK) * BK;
+    if (l->gemm_mode == DLRM_GEMM_F16X2)
+        if (int rc = operand_maxima(p, l->d_dz_absmax, l->M, l->N, l->d_x_absmax, l->M, l->K, s)) return rc;
     float *db_partial = slabs + (size_t)splits * l->N * l->K;
     if (splits == 1) {
         p.C = l->d_dw; p.ldc = l->dw_ld;

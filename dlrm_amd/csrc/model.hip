@@ -33,6 +33,7 @@ static int64_t padk(int64_t n) { return n <= 128 ? pad4(n) : (n + 127) / 128 * 1
 struct Layer {
     int N, K;
     int64_t w_off, w_ld, b_off;   // offsets into the flat parameter / gradient buffers
+    int s_x = -1, s_w = -1, s_dz = -1;   // f16x2 evaluation: slots of max |input|, max |W|, max |dz| in dlrm_model::amax
 };
 
 struct Act {   // a [B, n] activation: pointer + leading dimension
@@ -74,6 +75,11 @@ struct dlrm_model {
     int emb_col0 = 0, top_in = 0;
     std::vector<Act> bot_acts, bot_dz, top_acts, top_dz;
     float *pred = nullptr, *dpred = nullptr, *loss = nullptr;
+    // f16x2 evaluation of the big layers: largest magnitudes of their operands, one slot per tensor, zeroed at the start
+    // of every pass; amax_valid[slot] (host) = a kernel that fills the slot has been enqueued in this pass
+    float *amax = nullptr;
+    std::vector<char> amax_valid;
+    bool f16x2 = false;
     void *ws_dense = nullptr, *ws_sparse = nullptr, *ws_sparse_rw = nullptr;
     size_t ws_dense_bytes = 0, ws_sparse_bytes = 0, ws_sparse_rw_bytes = 0;
     float *a2a_send = nullptr, *a2a_recv = nullptr, *g_send = nullptr, *g_recv = nullptr, *rw_part = nullptr, *rw_local = nullptr;
@@ -157,29 +163,72 @@ static dlrm_embbag table_desc(const dlrm_model *m, bool rw, const void *d_indice
     return e;
 }
 
-static int linear_fwd(const dlrm_model *m, const Layer &l, const float *x, int64_t x_ld, float *y, int64_t y_ld, bool relu,
-                      hipStream_t s) {
+// ---- f16x2 evaluation: the operands' largest magnitudes travel with the tensors.  A GEMM's epilogue folds max |output|
+// into the slot of the tensor it writes; tensors that come out of other kernels (the interaction, the narrow layers,
+// the parameters after an SGD step) are measured by a pass of their own, enqueued right before their first reader.
+static bool big_layer(const dlrm_model *m, const Layer &l) { return m->f16x2 && !skinny_shape(l.N, l.K); }
+
+static int begin_pass_maxima(dlrm_model *m, hipStream_t s) {
+    if (!m->f16x2) return DLRM_OK;
+    DLRM_HIP(hipMemsetAsync(m->amax, 0, m->amax_valid.size() * sizeof(float), s));
+    std::fill(m->amax_valid.begin(), m->amax_valid.end(), 0);
+    return DLRM_OK;
+}
+
+static int need_max(dlrm_model *m, int slot, const float *x, int cols, int64_t ld, int64_t rows, hipStream_t s) {
+    if (slot < 0 || m->amax_valid[slot]) return DLRM_OK;
+    m->amax_valid[slot] = 1;
+    return dlrm_absmax(x, rows, cols, ld, m->amax + slot, s);
+}
+
+// slot of the tensor a GEMM writes (y_slot / dx_slot, -1: nobody needs it): returns the pointer and marks the slot filled
+static float *out_slot(dlrm_model *m, int slot) {
+    if (slot < 0) return nullptr;
+    m->amax_valid[slot] = 1;
+    return m->amax + slot;
+}
+
+static int linear_fwd(dlrm_model *m, const Layer &l, const float *x, int64_t x_ld, float *y, int64_t y_ld, bool relu,
+                      hipStream_t s, int y_slot = -1) {
     dlrm_linear d{};
     d.M = m->B; d.N = l.N; d.K = l.K; d.d_x = x; d.x_ld = x_ld; d.d_w = m->params + l.w_off; d.w_ld = l.w_ld;
     d.d_bias = m->params + l.b_off; d.d_y = y; d.y_ld = y_ld; d.act = relu ? DLRM_ACT_RELU : DLRM_ACT_NONE;
     d.gemm_mode = m->cfg.gemm_mode;
-    return timed(const_cast<dlrm_model *>(m), skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_FORWARD_SKINNY : DLRM_TIME_LINEAR_FORWARD, s,
+    if (big_layer(m, l)) {
+        if (int rc = need_max(m, l.s_x, x, l.K, x_ld, m->B, s)) return rc;
+        if (int rc = need_max(m, l.s_w, d.d_w, l.K, l.w_ld, l.N, s)) return rc;
+        d.gemm_mode = DLRM_GEMM_F16X2;
+        d.d_x_absmax = m->amax + l.s_x; d.d_w_absmax = m->amax + l.s_w; d.d_y_absmax = out_slot(m, y_slot);
+    }
+    return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_FORWARD_SKINNY : DLRM_TIME_LINEAR_FORWARD, s,
                  [&] { return dlrm_linear_forward(&d, s); });
 }
 
-static int linear_dgrad(const dlrm_model *m, const Layer &l, int64_t col0, int K, const float *dz, int64_t dz_ld, float *dx,
-                        int64_t dx_ld, const float *mask, int64_t mask_ld, hipStream_t s) {
+static int linear_dgrad(dlrm_model *m, const Layer &l, int64_t col0, int K, const float *dz, int64_t dz_ld, float *dx,
+                        int64_t dx_ld, const float *mask, int64_t mask_ld, hipStream_t s, int dx_slot = -1) {
     dlrm_linear_bwd d{};
     d.M = m->B; d.N = l.N; d.K = K; d.d_dz = dz; d.dz_ld = dz_ld; d.d_w = m->params + l.w_off + col0; d.w_ld = l.w_ld;
     d.d_dx = dx; d.dx_ld = dx_ld; d.d_relu_mask = mask; d.relu_mask_ld = mask_ld; d.gemm_mode = m->cfg.gemm_mode;
-    return timed(const_cast<dlrm_model *>(m), l.N == 1 ? DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY : DLRM_TIME_LINEAR_BACKWARD_DATA, s,
+    if (big_layer(m, l)) {
+        if (int rc = need_max(m, l.s_dz, dz, l.N, dz_ld, m->B, s)) return rc;
+        if (int rc = need_max(m, l.s_w, m->params + l.w_off, l.K, l.w_ld, l.N, s)) return rc;   // (of the whole matrix)
+        d.gemm_mode = DLRM_GEMM_F16X2;
+        d.d_dz_absmax = m->amax + l.s_dz; d.d_w_absmax = m->amax + l.s_w; d.d_dx_absmax = out_slot(m, dx_slot);
+    }
+    return timed(m, l.N == 1 ? DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY : DLRM_TIME_LINEAR_BACKWARD_DATA, s,
                  [&] { return dlrm_linear_backward_data(&d, s); });
 }
 
+// (the maxima of dz and x are in their slots by now: stack_backward sees to dz, the forward pass to x)
 static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, hipStream_t s) {
     dlrm_linear_bwd d{};
     d.M = m->B; d.N = l.N; d.K = l.K; d.d_dz = dz; d.dz_ld = dz_ld; d.d_x = x; d.x_ld = x_ld;
     d.d_dw = m->grads + l.w_off; d.dw_ld = l.w_ld; d.d_db = m->grads + l.b_off; d.gemm_mode = m->cfg.gemm_mode;
+    if (big_layer(m, l)) {
+        d.gemm_mode = DLRM_GEMM_F16X2;
+        d.d_dz_absmax = m->amax_valid[l.s_dz] ? m->amax + l.s_dz : nullptr;
+        d.d_x_absmax = m->amax_valid[l.s_x] ? m->amax + l.s_x : nullptr;
+    }
     return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY : DLRM_TIME_LINEAR_BACKWARD_WEIGHT, s,
                  [&] { return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s); });
 }
@@ -196,11 +245,13 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
         const int64_t dz_ld = i == n - 1 ? dz_last_ld : dz_bufs[i].ld;
         const float *x = i == 0 ? x_in : acts[i - 1].p;
         const int64_t xl = i == 0 ? x_in_ld : acts[i - 1].ld;
+        if (big_layer(m, st[i]))                          // (a dz that no GEMM wrote: measured here, ahead of both readers)
+            if (int rc = need_max(m, st[i].s_dz, dz, st[i].N, dz_ld, m->B, s)) return rc;
         if (int rc = wait_for(m, sw, s)) return rc;      // dz of this layer is complete
         if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw)) return rc;
         if (i > 0) {
             if (int rc = linear_dgrad(m, st[i], 0, st[i].K, dz, dz_ld, dz_bufs[i - 1].p, dz_bufs[i - 1].ld, acts[i - 1].p,
-                                      acts[i - 1].ld, s))
+                                      acts[i - 1].ld, s, big_layer(m, st[i - 1]) ? st[i - 1].s_dz : -1))
                 return rc;
         } else if (dx_first) {
             if (int rc = linear_dgrad(m, st[0], 0, st[0].K, dz, dz_ld, dx_first, dx_first_ld, nullptr, 0, s)) return rc;
@@ -307,6 +358,7 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
 
 static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, bool train, hipStream_t main) {
     hipStream_t emb = m->s_emb ? m->s_emb : main;
+    if (int rc = begin_pass_maxima(m, main)) return rc;
     if (train && m->cfg.presort) {
         hipStream_t prep = m->s_prep ? m->s_prep : main;
         if (int rc = wait_for(m, prep, main)) return rc;
@@ -331,7 +383,8 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
     const float *x = m->x_dense;
     int64_t xl = m->x_ld;
     for (size_t i = 0; i < m->bot.size(); i++) {
-        if (int rc = linear_fwd(m, m->bot[i], x, xl, m->bot_acts[i].p, m->bot_acts[i].ld, true, main)) return rc;
+        const int y_slot = i + 1 < m->bot.size() && big_layer(m, m->bot[i + 1]) ? m->bot[i + 1].s_x : -1;
+        if (int rc = linear_fwd(m, m->bot[i], x, xl, m->bot_acts[i].p, m->bot_acts[i].ld, true, main, y_slot)) return rc;
         x = m->bot_acts[i].p; xl = m->bot_acts[i].ld;
     }
     if (m->gather) {
@@ -356,7 +409,8 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
     x = m->inter; xl = m->inter_ld;
     for (size_t i = 0; i < m->topl.size(); i++) {
         const bool relu = m->cfg.final_relu || i + 1 < m->topl.size();
-        if (int rc = linear_fwd(m, m->topl[i], x, xl, m->top_acts[i].p, m->top_acts[i].ld, relu, main)) return rc;
+        const int y_slot = i + 1 < m->topl.size() && big_layer(m, m->topl[i + 1]) ? m->topl[i + 1].s_x : -1;
+        if (int rc = linear_fwd(m, m->topl[i], x, xl, m->top_acts[i].p, m->top_acts[i].ld, relu, main, y_slot)) return rc;
         x = m->top_acts[i].p; xl = m->top_acts[i].ld;
     }
     return DLRM_OK;
@@ -510,6 +564,17 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     build_stack(bsz, off, m->bot);
     build_stack(tsz, off, m->topl);
     m->n_params = off;
+    // the big layers' products on f16 pieces when the batch is large enough for the matrix pipe to be the limit (local
+    // batch 8192: +2 %, 16384: +12 %, 65536: +29 %; at Criteo-Kaggle's 2048 the layers are short launches whose time
+    // the measuring passes only add to: -6 %)
+    m->f16x2 = c->gemm_mode == DLRM_GEMM_F16X2 || (c->gemm_mode == DLRM_GEMM_DEFAULT && m->B >= 8192);
+    {
+        int n_slots = 0;
+        for (auto *st : {&m->bot, &m->topl})
+            for (Layer &l : *st) { l.s_x = n_slots++; l.s_w = n_slots++; l.s_dz = n_slots++; }
+        m->amax_valid.assign((size_t)n_slots, 0);
+        if ((rc = dalloc(m, &m->amax, (size_t)n_slots))) return fail(rc);
+    }
     if ((rc = dalloc(m, &m->params, (size_t)off))) return fail(rc);
     if ((rc = dalloc(m, &m->grads, (size_t)off))) return fail(rc);
 

@@ -19,7 +19,7 @@ def _stream():
 # While a StepRecorder is installed (dlrm_amd.plan), the operators below do everything except launch:
 # their C-ABI call is handed to the recorder, which appends it to a dlrm_plan.
 _recorder = None
-_gemm_mode = 0 if os.environ.get("DLRM_GEMM_MODE", "1").strip() == "0" else 1
+_gemm_mode = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("DLRM_GEMM_MODE", "1").strip(), 1)
 
 
 def _emit(name, *args):
@@ -207,9 +207,11 @@ def _ld(t):
 
 
 @_op
-def linear_forward(x, w, bias, relu, out=None):
+def linear_forward(x, w, bias, relu, out=None, x_absmax=None, w_absmax=None, y_absmax=None):
     """y = act(x W^T + b).  x [M,K] and w [N,K] may be column slices of wider
-    (padded) buffers: the row stride is passed as the leading dimension."""
+    (padded) buffers: the row stride is passed as the leading dimension.
+    *_absmax (f16x2 mode): one-element float32 tensors holding max |x|, max |W| (None: measured by the call) and
+    receiving max |y| (atomicMax: zero it first)."""
     _require_cuda(x, w, bias, out)
     M, K = x.shape
     N = w.shape[0]
@@ -224,13 +226,14 @@ def linear_forward(x, w, bias, relu, out=None):
     d.d_y, d.y_ld = out.data_ptr(), _ld(out)
     d.act = _capi.ACT_RELU if relu else _capi.ACT_NONE
     d.gemm_mode = _gemm_field()
+    d.d_x_absmax, d.d_w_absmax, d.d_y_absmax = _ptr0(x_absmax), _ptr0(w_absmax), _ptr0(y_absmax)
     _emit("linear_forward", d)
     return out
 
 
 @_op
-def linear_backward_data(dz, w, relu_mask=None, out=None):
-    """dx = dz W, optionally masked with (relu_mask > 0)."""
+def linear_backward_data(dz, w, relu_mask=None, out=None, dz_absmax=None, w_absmax=None, dx_absmax=None):
+    """dx = dz W, optionally masked with (relu_mask > 0).  *_absmax: see linear_forward."""
     _require_cuda(dz, w, relu_mask, out)
     M, N = dz.shape
     K = w.shape[1]
@@ -244,8 +247,22 @@ def linear_backward_data(dz, w, relu_mask=None, out=None):
     if relu_mask is not None:
         d.d_relu_mask, d.relu_mask_ld = relu_mask.data_ptr(), _ld(relu_mask)
     d.gemm_mode = _gemm_field()
+    d.d_dz_absmax, d.d_w_absmax, d.d_dx_absmax = _ptr0(dz_absmax), _ptr0(w_absmax), _ptr0(dx_absmax)
     _emit("linear_backward_data", d)
     return out
+
+
+def _ptr0(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def absmax_(x, slot):
+    """max |x| of a 2-D float32 tensor (rows may be strided) folded into the one-element tensor `slot` (atomic maximum:
+    zero it to start a new measurement)."""
+    _require_cuda(x, slot)
+    assert x.dim() == 2 and x.dtype == torch.float32 and slot.dtype == torch.float32 and slot.numel() == 1
+    check(_capi.lib().dlrm_absmax(_ptr(x), C.c_int64(x.shape[0]), C.c_int32(x.shape[1]), C.c_int64(_ld(x)), _ptr(slot), _stream()))
+    return slot
 
 
 def linear_backward_weight_workspace_bytes(M, N, K):
@@ -255,8 +272,8 @@ def linear_backward_weight_workspace_bytes(M, N, K):
 
 
 @_op
-def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True):
-    """dW = dz^T x [N,K], db = column sums of dz."""
+def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True, dz_absmax=None, x_absmax=None):
+    """dW = dz^T x [N,K], db = column sums of dz.  *_absmax: see linear_forward."""
     _require_cuda(dz, x, dw, db, workspace)
     M, N = dz.shape
     K = x.shape[1]
@@ -274,6 +291,7 @@ def linear_backward_weight(dz, x, dw=None, db=None, workspace=None, want_db=True
     d.d_dw, d.dw_ld = dw.data_ptr(), _ld(dw)
     d.d_db = 0 if db is None else db.data_ptr()
     d.gemm_mode = _gemm_field()
+    d.d_dz_absmax, d.d_x_absmax = _ptr0(dz_absmax), _ptr0(x_absmax)
     _emit("linear_backward_weight", d, _ptr(workspace), C.c_size_t(workspace.numel()))
     return dw, db, workspace
 
@@ -448,10 +466,11 @@ def set_gemm_mode(mode):
     """How the linear operators issued from now on evaluate their float32 products (a field of every layer
     descriptor, so a recorded step keeps the mode it was recorded with): 0 float32 MFMA
     (v_mfma_f32_32x32x2_f32); 1 exact bf16x3 split products on the bf16 MFMA with float32 accumulation
-    (float32 accuracy, 8/3 of the matrix-pipe rate; the default).  Environment: DLRM_GEMM_MODE=0|1."""
+    (float32 accuracy, 8/3 of the matrix-pipe rate; the default); 2 two-piece f16 splits of the operands scaled by
+    a power of two (three cross terms, representation error near one float32 ulp).  Environment: DLRM_GEMM_MODE=0|1|2."""
     global _gemm_mode
-    if int(mode) not in (0, 1):
-        raise ValueError("gemm mode must be 0 (float32 MFMA) or 1 (bf16x3 split)")
+    if int(mode) not in (0, 1, 2):
+        raise ValueError("gemm mode must be 0 (float32 MFMA), 1 (bf16x3 split) or 2 (f16x2 split)")
     _gemm_mode = int(mode)
 
 
@@ -460,4 +479,4 @@ def get_gemm_mode():
 
 
 def _gemm_field():
-    return _capi.GEMM_F32_MFMA if _gemm_mode == 0 else _capi.GEMM_BF16X3
+    return (_capi.GEMM_F32_MFMA, _capi.GEMM_BF16X3, _capi.GEMM_F16X2)[_gemm_mode]

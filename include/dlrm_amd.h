@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1012
+#define DLRM_ABI_VERSION 1013
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -186,10 +186,21 @@ int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_
  *      2^-26 of a product, so the result has float32 accuracy (element by element within a few 2^-24 of
  *      sum_k |a_ik b_kj|, like a float32 fma chain) at 8/3 of the float32 matrix-pipe rate.
  *   DLRM_GEMM_F32_MFMA: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered float32 fma chain.
+ *   DLRM_GEMM_F16X2: each operand is multiplied by the power of two that puts its largest magnitude just below
+ *      2^14 and every element is split into two f16 pieces (h = f16(x s), l = f16(x s - h): 22 mantissa bits); the
+ *      three leading cross terms run on v_mfma_f32_32x32x16_f16 with float32 accumulation and the result is scaled
+ *      back.  The representation error is about one float32 ulp of each product (7.5e-8 relative rms, against a
+ *      float64 product; the float32 accumulation of ANY of the modes, this one included, contributes 2e-7 to 4e-7 at
+ *      reduction lengths of 512 to 65536), at half the matrix work of BF16X3: 1.4 to 1.65 times faster on the
+ *      65536-row layers.  It needs max |x| of both operands before the kernel starts: handed in through the
+ *      descriptor's *_absmax fields (a GEMM of this library can leave its output's maximum behind for the next
+ *      one), else measured by a pass over the operand inside the call, which costs about what the mode gains.
+ *      dlrm_model_* uses it for the layers of models with a local batch of 8192 and above when its gemm_mode is
+ *      DLRM_GEMM_DEFAULT.
  * The mode is a field of the layer descriptor: a recorded step (dlrm_plan) keeps the mode it was recorded
  * with, and two host threads can use different modes.
  */
-enum { DLRM_GEMM_DEFAULT = 0, DLRM_GEMM_F32_MFMA = 1, DLRM_GEMM_BF16X3 = 2 };
+enum { DLRM_GEMM_DEFAULT = 0, DLRM_GEMM_F32_MFMA = 1, DLRM_GEMM_BF16X3 = 2, DLRM_GEMM_F16X2 = 3 };
 
 /*
  * y = act(x W^T + bias): one torch::nn::Linear + torch::relu of Net2::forward
@@ -213,9 +224,20 @@ typedef struct dlrm_linear {
     int64_t y_ld;
     int32_t act;        /* DLRM_ACT_NONE | DLRM_ACT_RELU */
     int32_t gemm_mode;  /* DLRM_GEMM_* */
+    /* DLRM_GEMM_F16X2 only, each may be NULL: device scalars holding max |x| and max |W| (NULL: the call measures
+     * the operand in a pass of its own), and a scalar into which max |y| is folded with atomicMax (start it at 0) */
+    const float *d_x_absmax, *d_w_absmax;
+    float *d_y_absmax;
 } dlrm_linear;
 
 int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream);
+
+/*
+ * max |x| over a [rows, cols] float32 matrix (row stride ld), folded into *d_slot with an atomic maximum on the bit
+ * pattern: the slot must hold 0 (or an earlier maximum that is to be kept).  No counterpart in the reference; it
+ * produces the operand maxima DLRM_GEMM_F16X2 takes for tensors that no GEMM of this library wrote.
+ */
+int dlrm_absmax(const float *d_x, int64_t rows, int32_t cols, int64_t ld, float *d_slot, dlrm_stream_t stream);
 
 /*
  * Backward of the same layer; replaces the autograd pass loss.backward()
@@ -248,6 +270,10 @@ typedef struct dlrm_linear_bwd {
     int64_t dw_ld;
     float *d_db;        /* [N] or NULL (backward_weight) */
     int32_t gemm_mode;  /* DLRM_GEMM_* */
+    /* DLRM_GEMM_F16X2 only, each may be NULL (see dlrm_linear): max |dz|, max |W| (backward_data), max |x|
+     * (backward_weight); max |dx| is folded into *d_dx_absmax (backward_data) */
+    const float *d_dz_absmax, *d_w_absmax, *d_x_absmax;
+    float *d_dx_absmax;
 } dlrm_linear_bwd;
 
 int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream);

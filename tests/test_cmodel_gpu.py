@@ -36,9 +36,14 @@ def local_batch_ids(m, cfg, idx, off, B):
 @pytest.mark.parametrize("name", ["mlperf_like", "kaggle_like", "rmc1_like", "adagrad_bf16rows_off"])
 @pytest.mark.parametrize("mode", ["single", "exchange", "exchange-rw"])
 @pytest.mark.parametrize("ragged", [False, True])
-def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged):
-    from dlrm_amd import comm
+@pytest.mark.parametrize("gemm", ["default", "f16x2"])
+def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged, gemm):
+    """gemm = f16x2: the big layers' products on two f16 pieces per operand with the operands' maxima travelling from
+    kernel to kernel (what the model picks by itself from a local batch of 8192 up), same tolerance."""
+    from dlrm_amd import _capi, comm
     from dlrm_amd.cmodel import CModel
+    if gemm == "f16x2" and (mode == "exchange-rw" or ragged):
+        pytest.skip("the evaluation mode does not touch the sparse path: covered at the other corners")
     cfg = small_cfgs()[name]
     B, T = 37, cfg.num_tables
     cm, owner = None, None
@@ -47,7 +52,8 @@ def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged):
         if mode == "exchange-rw":      # the two largest tables are split by rows (one range: the only rank's)
             big = sorted(range(T), key=lambda t: -cfg.table_rows[t])[:2]
             owner = [-1 if t in big else 0 for t in range(T)]
-    m = CModel(cfg, B, comm=cm, table_owner=owner, seed=3, force_exchange=mode != "single", idx_dtype=torch.int64)
+    m = CModel(cfg, B, comm=cm, table_owner=owner, seed=3, force_exchange=mode != "single", idx_dtype=torch.int64,
+               gemm_mode=_capi.GEMM_F16X2 if gemm == "f16x2" else 0)
     m.init_dense(7)
     Ws, bs = m.get_dense()
     if name == "rmc1_like":            # positive biases keep the all-ReLU reference model alive

@@ -14,9 +14,10 @@ from tests.test_embbag_forward_gpu import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x3"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["f32mfma", "bf16x3", "f16x2"], autouse=True)
 def gemm_mode(request):
-    """every test of this file runs with both evaluations of the float32 products"""
+    """every test of this file runs with the three evaluations of the float32 products (f16x2 here without operand
+    maxima in the descriptors: the call measures them itself)"""
     from dlrm_amd import ops
     old = ops.get_gemm_mode()
     ops.set_gemm_mode(request.param)
@@ -350,3 +351,55 @@ def test_losses(oracle, n):
     lm1, _ = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True, want_grad=False)
     _, dm1 = ops.loss_mse(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), relu_mask_pred=True, want_loss=False)
     assert torch.equal(lm1, lm) and torch.equal(dm1, dmm)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1, 1, 1), (7, 5, 5), (300, 479, 480), (2048, 512, 512), (4097, 128, 3456),
+                                          (1000, 13, 16), (65536, 256, 256)])
+def test_absmax_is_the_largest_magnitude(rows, cols, ld, gemm_mode):
+    from dlrm_amd import ops
+    if gemm_mode != 2:
+        pytest.skip("one run is enough")
+    gen = torch.Generator(device="cuda").manual_seed(rows + cols)
+    buf = torch.randn(rows, ld, device="cuda", generator=gen) * 3.0
+    buf[:, cols:] = 1e9                      # what lies between cols and ld is not part of the matrix
+    x = buf[:, :cols]
+    x[rows // 2, cols // 3] = -77.5          # a negative extreme
+    slot = torch.zeros(1, device="cuda")
+    ops.absmax_(x, slot)
+    assert slot.item() == 77.5
+    ops.absmax_(x * 0.5, slot)               # a smaller matrix leaves the slot alone
+    assert slot.item() == 77.5
+    un = torch.randn(rows * cols + 1, device="cuda", generator=gen)[1:].reshape(rows, cols)   # rows off 16-byte boundaries
+    slot.zero_()
+    ops.absmax_(un, slot)
+    assert slot.item() == un.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1024, 479), (2048, 256, 512), (130, 130, 130)])
+def test_f16x2_with_maxima_handed_in_equals_the_measuring_call(M, N, K, gemm_mode):
+    """The operands' maxima only choose the power-of-two scales: handed in through the descriptor (as the hosted model
+    does, from the epilogue of the GEMM that wrote the operand) or measured inside the call, the products are the
+    same bits; a maximum that is too large by a factor below 2^10 still gives a float32-grade product; and the
+    epilogue leaves max |y| behind for the next layer."""
+    from dlrm_amd import ops
+    if gemm_mode != 2:
+        pytest.skip("f16x2 only")
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = padded(torch.relu(torch.randn(M, K, device="cuda", generator=gen)).cpu().numpy())
+    w = padded((torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5).cpu().numpy())
+    b = torch.randn(N, device="cuda", generator=gen)
+    dz = padded((torch.randn(M, N, device="cuda", generator=gen) * 1e-5).cpu().numpy())
+    ax, aw, adz = (t.abs().max().reshape(1).clone() for t in (x, w, dz))
+    ay, adx = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    y0 = ops.linear_forward(x, w, b, True)
+    y1 = ops.linear_forward(x, w, b, True, x_absmax=ax, w_absmax=aw, y_absmax=ay)
+    dx0 = ops.linear_backward_data(dz, w, relu_mask=x)
+    dx1 = ops.linear_backward_data(dz, w, relu_mask=x, dz_absmax=adz, w_absmax=aw, dx_absmax=adx)
+    dw0, db0, _ = ops.linear_backward_weight(dz, x)
+    dw1, db1, _ = ops.linear_backward_weight(dz, x, dz_absmax=adz, x_absmax=ax)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    assert ay.item() == y1.abs().max().item() and adx.item() == dx1.abs().max().item()
+    y2 = ops.linear_forward(x, w, b, True, x_absmax=ax * 900.0, w_absmax=aw * 3.0)
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert ((y2.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
