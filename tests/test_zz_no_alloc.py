@@ -26,7 +26,7 @@ def _case(M, N, K, seed):
     assert float((dw.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("mode", [1, 0], ids=["bf16x3", "f32mfma"])
+@pytest.mark.parametrize("mode", [1, 0, 2], ids=["bf16x3", "f32mfma", "f16x2"])
 def test_static_scratch_entry_point_matches_workspace_entry_point(mode):
     from dlrm_amd import _capi, ops
     old = ops.get_gemm_mode()

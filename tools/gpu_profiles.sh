@@ -57,7 +57,7 @@ for w in $WHAT; do
         "$OUT/hbm_traffic.json" mlperf:65536
       ;;
     mfma)   # matrix-pipe busy cycles of the GEMM kernels in the step, at both batch sizes, and where their waves wait
-      M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
+      M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE"
       W="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
       pmc mfma_b65536 "$M" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
       pmc mfma_b8192 "$M" python3 $ROOT/bench.py --global-batch 8192 --steps 2 --warmup 1 --no-cpu-baseline

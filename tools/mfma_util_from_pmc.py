@@ -27,7 +27,8 @@ def mfma(path):
         out[short(k)] = {"dispatches": n, "avg_us_under_pmc": round(us, 1),
                          "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / 1024.0 / n / act, 3),
                          "clock_GHz": round(act / (us * 1e3), 2),
-                         "bf16_mfma_per_dispatch": c["SQ_INSTS_VALU_MFMA_MOPS_BF16"]["sum"] / n}
+                         "bf16_mfma_per_dispatch": c["SQ_INSTS_VALU_MFMA_MOPS_BF16"]["sum"] / n,
+                         "f16_mfma_per_dispatch": c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", {"sum": 0})["sum"] / n}
     return out
 
 
@@ -47,7 +48,7 @@ def waits(path, into):
 
 def main():
     b64, b8, wait, out = sys.argv[1:5]
-    res = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -- "
+    res = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -- "
                       "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline [--global-batch 8192]; second pass: SQ_WAVE_CYCLES "
                       "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
                       "(batch 65536); tools/mfma_util_from_pmc.py",

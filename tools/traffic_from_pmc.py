@@ -20,13 +20,14 @@ import sys
 
 # kernel-name fragment -> (operator, counts as one operator launch?)
 RULES = [
-    ("gemm_bf16x3_kernel<true, true", "linear_forward", True),
+    ("gemm_split_kernel<true, true", "linear_forward", True),
     ("gemm_f32_kernel<true, true", "linear_forward", True),
-    ("gemm_bf16x3_kernel<true, false", "linear_backward_data", True),
+    ("gemm_split_kernel<true, false", "linear_backward_data", True),
     ("gemm_f32_kernel<true, false", "linear_backward_data", True),
-    ("gemm_bf16x3_kernel<false, false", "linear_backward_weight", True),
+    ("gemm_split_kernel<false, false", "linear_backward_weight", True),
     ("gemm_f32_kernel<false, false", "linear_backward_weight", True),
     ("reduce_slabs_kernel", "linear_backward_weight", False),
+    ("absmax_kernel", "operand_maxima", True),
     ("skinny_k_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_bwd_data_kernel", "linear_backward_data_skinny", True),
