@@ -86,6 +86,28 @@ __device__ inline void split2_pair(f32x2 x, float scale, unsigned &h, unsigned &
     l = __builtin_bit_cast(unsigned, lh);
 }
 
+// max |x| of several [rows, cols] matrices (row stride ld) folded into their slots by one launch per kAbsmaxMany
+// matrices (gemm_f32.hip; the hosted model measures its weight matrices with it)
+constexpr int kAbsmaxMany = 16;
+struct AbsmaxItem {
+    const float *x;
+    int64_t rows;
+    int cols;
+    int64_t ld;
+    float *slot;
+};
+int absmax_many(const AbsmaxItem *items, int n, hipStream_t s);
+
+// Folds the largest magnitude a wave has seen (per-lane `vmax` >= 0) into *slot: one wave reduction, at most one atomic
+// per wave and only if it can still raise the slot (thousands of atomics on one address queue up behind each other;
+// a stale read costs one atomic too many, never a wrong result).  Every lane of the wave must call it.
+__device__ inline void fold_absmax(float vmax, float *slot) {
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned *>(slot))
+        atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(vmax));
+}
+
 // power-of-two scale for an operand whose largest magnitude has the float32 bits `absmax_bits`: the scaled maximum
 // lands in [2^13, 2^14); zero / denormal maxima scale by 2^127, infinities and NaNs by 2^-115 (the product is then
 // whatever float32 arithmetic makes of them)

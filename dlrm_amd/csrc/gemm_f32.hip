@@ -226,13 +226,7 @@ __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI]
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    if (p.c_max != nullptr) {     // (non-negative floats order like their bit patterns; a NaN counts as huge)
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
-        // (only if it can still raise the slot: see absmax_kernel)
-        if (lane == 0 && __float_as_uint(vmax) > *reinterpret_cast<volatile unsigned *>(p.c_max))
-            atomicMax(reinterpret_cast<unsigned *>(p.c_max), __float_as_uint(vmax));
-    }
+    if (p.c_max != nullptr) fold_absmax(vmax, p.c_max);   // (non-negative floats order like their bit patterns)
 }
 
 // 64 MFMAs: one 32-deep reduction step of the wave's 64x64 output
@@ -916,24 +910,31 @@ static void launch_split(const GemmParams &p, int pieces, unsigned nwg, hipStrea
 
 // ---- largest magnitude of an operand (f16x2 evaluation): one pass over a [rows, cols] matrix, folded into *slot with
 // atomicMax on the bit patterns (non-negative floats order like unsigned integers; the slot must start at 0)
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t rows, int cols, int64_t ld, int vec,
-                                                      int lanes_per_row, unsigned *__restrict__ slot) {
-    // lanes_per_row (a power of two, at most 64) lanes share a row; a wave takes 64 / lanes_per_row rows at a time
+struct AbsmaxJob {
+    const float *x;
+    int64_t rows, ld;
+    int cols, vec, lanes_per_row;   // vec: rows start on 16-byte boundaries; lanes_per_row: a power of two, at most 64
+    unsigned *slot;
+};
+struct AbsmaxJobs { AbsmaxJob j[kAbsmaxMany]; };
+
+// lanes_per_row lanes share a row; a wave takes 64 / lanes_per_row rows at a time; workgroup `block` of `n_blocks`
+__device__ inline void absmax_rows(const AbsmaxJob &a, int64_t block, int64_t n_blocks) {
     const int lane = threadIdx.x & 63;
-    const int lr = lane / lanes_per_row, lc = lane % lanes_per_row;
-    const int rows_per_wave = 64 / lanes_per_row;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    const int cols4 = vec ? cols / 4 : 0;     // 16-byte pieces per row (rows start on 16-byte boundaries)
+    const int lr = lane / a.lanes_per_row, lc = lane % a.lanes_per_row;
+    const int rows_per_wave = 64 / a.lanes_per_row;
+    const int64_t wave = block * 4 + (threadIdx.x >> 6), n_waves = n_blocks * 4;
+    const int cols4 = a.vec ? a.cols / 4 : 0;     // 16-byte pieces per row
     unsigned m = 0;
-    for (int64_t r = wave * rows_per_wave + lr; r < rows; r += n_waves * rows_per_wave) {
-        const float *row = x + r * ld;
-        for (int c = lc; c < cols4; c += lanes_per_row) {
+    for (int64_t r = wave * rows_per_wave + lr; r < a.rows; r += n_waves * rows_per_wave) {
+        const float *row = a.x + r * a.ld;
+        for (int c = lc; c < cols4; c += a.lanes_per_row) {
             const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);
-            const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
-            const unsigned c2 = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
-            m = max(max(m, max(a, b)), max(c2, d));
+            const unsigned p = __float_as_uint(v.x) & 0x7fffffffu, q = __float_as_uint(v.y) & 0x7fffffffu;
+            const unsigned t = __float_as_uint(v.z) & 0x7fffffffu, u = __float_as_uint(v.w) & 0x7fffffffu;
+            m = max(max(m, max(p, q)), max(t, u));
         }
-        for (int c = 4 * cols4 + lc; c < cols; c += lanes_per_row) m = max(m, __float_as_uint(row[c]) & 0x7fffffffu);
+        for (int c = 4 * cols4 + lc; c < a.cols; c += a.lanes_per_row) m = max(m, __float_as_uint(row[c]) & 0x7fffffffu);
     }
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, k, 64));
@@ -944,21 +945,49 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (m > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, m);
+        if (m > *reinterpret_cast<volatile unsigned *>(a.slot)) atomicMax(a.slot, m);
     }
 }
 
+__global__ __launch_bounds__(256) void absmax_kernel(AbsmaxJob a) { absmax_rows(a, blockIdx.x, gridDim.x); }
+
+// several small matrices (a model's weight matrices) in one launch: blockIdx.y picks the matrix
+__global__ __launch_bounds__(256) void absmax_many_kernel(AbsmaxJobs jobs) { absmax_rows(jobs.j[blockIdx.y], blockIdx.x, gridDim.x); }
+
+static AbsmaxJob absmax_job(const float *x, int64_t rows, int cols, int64_t ld, float *slot, int64_t *blocks) {
+    AbsmaxJob a{};
+    a.x = x; a.rows = rows; a.ld = ld; a.cols = cols; a.slot = reinterpret_cast<unsigned *>(slot);
+    a.vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ld % 4 == 0;
+    const int per_row = a.vec ? (cols + 3) / 4 : cols;
+    a.lanes_per_row = 1;
+    while (a.lanes_per_row < 64 && a.lanes_per_row < per_row) a.lanes_per_row <<= 1;
+    const int64_t b = ceil_div(ceil_div(rows, 64 / a.lanes_per_row), 4);
+    *blocks = b < 1 ? 1 : (b > 2048 ? 2048 : b);
+    return a;
+}
+
 static int launch_absmax(const float *x, int64_t rows, int cols, int64_t ld, float *slot, hipStream_t s) {
-    const int vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ld % 4 == 0;
-    const int per_row = vec ? (cols + 3) / 4 : cols;
-    int lanes = 1;
-    while (lanes < 64 && lanes < per_row) lanes <<= 1;
-    const int64_t waves = ceil_div(rows, 64 / lanes);
-    int64_t blocks = ceil_div(waves, 4);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, cols, ld, vec, lanes,
-                       reinterpret_cast<unsigned *>(slot));
+    int64_t blocks = 1;
+    const AbsmaxJob a = absmax_job(x, rows, cols, ld, slot, &blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+int absmax_many(const AbsmaxItem *items, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += kAbsmaxMany) {
+        AbsmaxJobs jobs{};
+        const int cnt = n - i0 < kAbsmaxMany ? n - i0 : kAbsmaxMany;
+        int64_t most = 1;
+        for (int i = 0; i < cnt; i++) {
+            int64_t b = 1;
+            jobs.j[i] = absmax_job(items[i0 + i].x, items[i0 + i].rows, items[i0 + i].cols, items[i0 + i].ld, items[i0 + i].slot, &b);
+            most = b > most ? b : most;
+        }
+        most = most > 64 ? 64 : most;     // (small matrices: a few dozen workgroups each)
+        hipLaunchKernelGGL(absmax_many_kernel, dim3((unsigned)most, (unsigned)cnt), dim3(256), 0, s, jobs);
+        DLRM_LAUNCH_CHECK();
+    }
     return DLRM_OK;
 }
 
@@ -1058,7 +1087,7 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     // the two shapes that are no matrix product: a few input columns, or one output column
     if (skinny_k_forward_ok(l->N, l->K))
         return skinny_k_forward(l->d_x, l->x_ld, l->d_w, l->w_ld, l->d_bias, l->d_y, l->y_ld, (int)l->M, l->N, l->K,
-                                l->act == DLRM_ACT_RELU, as_stream(stream));
+                                l->act == DLRM_ACT_RELU, l->d_y_absmax, as_stream(stream));
     if (l->N == 1 && gemv_ok(l->d_x, l->x_ld, l->d_w, l->K))
         return gemv_forward(l->d_x, l->x_ld, l->d_w, l->d_bias, l->d_y, l->y_ld, (int)l->M, l->K, l->act == DLRM_ACT_RELU,
                             as_stream(stream));
@@ -1083,7 +1112,7 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     if (l->N == 1 && gemv_ok(l->d_dx, l->dx_ld, l->d_w, l->K) &&
         (l->d_relu_mask == nullptr || gemv_ok(l->d_relu_mask, l->relu_mask_ld, l->d_w, l->K)))
         return gemv_backward_data(l->d_dz, l->dz_ld, l->d_w, l->d_dx, l->dx_ld, l->d_relu_mask, l->relu_mask_ld, (int)l->M,
-                                  l->K, as_stream(stream));
+                                  l->K, l->d_dx_absmax, as_stream(stream));
     GemmParams p{};
     p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_dx; p.ldc = l->dx_ld;
     p.M = (int)l->M; p.N = l->K; p.K = l->N;  // C = dx [M,K], reduction over N

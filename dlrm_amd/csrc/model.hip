@@ -172,7 +172,15 @@ static int begin_pass_maxima(dlrm_model *m, hipStream_t s) {
     if (!m->f16x2) return DLRM_OK;
     DLRM_HIP(hipMemsetAsync(m->amax, 0, m->amax_valid.size() * sizeof(float), s));
     std::fill(m->amax_valid.begin(), m->amax_valid.end(), 0);
-    return DLRM_OK;
+    // the weight matrices of the big layers, one launch (they change once per step, in the SGD kernel)
+    std::vector<AbsmaxItem> items;
+    for (auto *st : {&m->bot, &m->topl})
+        for (const Layer &l : *st)
+            if (big_layer(m, l)) {
+                items.push_back(AbsmaxItem{m->params + l.w_off, l.N, l.K, l.w_ld, m->amax + l.s_w});
+                m->amax_valid[l.s_w] = 1;
+            }
+    return items.empty() ? DLRM_OK : absmax_many(items.data(), (int)items.size(), s);
 }
 
 static int need_max(dlrm_model *m, int slot, const float *x, int cols, int64_t ld, int64_t rows, hipStream_t s) {
@@ -198,8 +206,9 @@ static int linear_fwd(dlrm_model *m, const Layer &l, const float *x, int64_t x_l
         if (int rc = need_max(m, l.s_x, x, l.K, x_ld, m->B, s)) return rc;
         if (int rc = need_max(m, l.s_w, d.d_w, l.K, l.w_ld, l.N, s)) return rc;
         d.gemm_mode = DLRM_GEMM_F16X2;
-        d.d_x_absmax = m->amax + l.s_x; d.d_w_absmax = m->amax + l.s_w; d.d_y_absmax = out_slot(m, y_slot);
+        d.d_x_absmax = m->amax + l.s_x; d.d_w_absmax = m->amax + l.s_w;
     }
+    if (m->f16x2) d.d_y_absmax = out_slot(m, y_slot);    // (the narrow layers' kernels leave their maximum behind too)
     return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_FORWARD_SKINNY : DLRM_TIME_LINEAR_FORWARD, s,
                  [&] { return dlrm_linear_forward(&d, s); });
 }
@@ -213,8 +222,9 @@ static int linear_dgrad(dlrm_model *m, const Layer &l, int64_t col0, int K, cons
         if (int rc = need_max(m, l.s_dz, dz, l.N, dz_ld, m->B, s)) return rc;
         if (int rc = need_max(m, l.s_w, m->params + l.w_off, l.K, l.w_ld, l.N, s)) return rc;   // (of the whole matrix)
         d.gemm_mode = DLRM_GEMM_F16X2;
-        d.d_dz_absmax = m->amax + l.s_dz; d.d_w_absmax = m->amax + l.s_w; d.d_dx_absmax = out_slot(m, dx_slot);
+        d.d_dz_absmax = m->amax + l.s_dz; d.d_w_absmax = m->amax + l.s_w;
     }
+    if (m->f16x2) d.d_dx_absmax = out_slot(m, dx_slot);
     return timed(m, l.N == 1 ? DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY : DLRM_TIME_LINEAR_BACKWARD_DATA, s,
                  [&] { return dlrm_linear_backward_data(&d, s); });
 }

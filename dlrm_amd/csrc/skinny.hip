@@ -24,8 +24,9 @@ __global__ __launch_bounds__(kSkThreads) void skinny_k_fwd_kernel(const float *_
                                                                    const float *__restrict__ w, int64_t w_ld,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int64_t y_ld, int M, int N, int K, int relu,
-                                                                   int rows_per_block) {
+                                                                   int rows_per_block, float *__restrict__ y_max) {
     __shared__ float sx[kSkRows][kSkinnyK];
+    float vmax = 0.f;
     const int n = blockIdx.x * kSkThreads + threadIdx.x;
     const int m_begin = blockIdx.y * rows_per_block;
     const int m_end = min(M, m_begin + rows_per_block);
@@ -44,9 +45,12 @@ __global__ __launch_bounds__(kSkThreads) void skinny_k_fwd_kernel(const float *_
             float a = b;
 #pragma unroll
             for (int k = 0; k < kSkinnyK; k++) a = fmaf(sx[r][k], wr[k], a);
-            y[(int64_t)(m0 + r) * y_ld + n] = relu ? fmaxf(a, 0.f) : a;
+            a = relu ? fmaxf(a, 0.f) : a;
+            y[(int64_t)(m0 + r) * y_ld + n] = a;
+            vmax = fmaxf(vmax, fabsf(a));
         }
     }
+    if (y_max != nullptr) fold_absmax(vmax, y_max);
 }
 
 // the same walk with the roles swapped: dz[m][n] streams in (coalesced), x[m][:] comes from LDS, the thread keeps
@@ -130,9 +134,11 @@ __global__ __launch_bounds__(kSkThreads) void gemv_fwd_kernel(const float *__res
 __global__ __launch_bounds__(kSkThreads) void gemv_bwd_data_kernel(const float *__restrict__ dz, int64_t dz_ld,
                                                                     const float *__restrict__ w, float *__restrict__ dx,
                                                                     int64_t dx_ld, const float *__restrict__ mask,
-                                                                    int64_t mask_ld, int M, int K) {
+                                                                    int64_t mask_ld, int M, int K,
+                                                                    float *__restrict__ dx_max) {
     const int kq = K >> 2;
     const int64_t total = (int64_t)M * kq;
+    float vmax = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * kSkThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kSkThreads) {
         const int64_t m = i / kq;
         const int k = (int)(i - m * kq) * 4;
@@ -144,7 +150,9 @@ __global__ __launch_bounds__(kSkThreads) void gemv_bwd_data_kernel(const float *
             r.x = q.x > 0.f ? r.x : 0.f; r.y = q.y > 0.f ? r.y : 0.f; r.z = q.z > 0.f ? r.z : 0.f; r.w = q.w > 0.f ? r.w : 0.f;
         }
         *reinterpret_cast<float4 *>(dx + m * dx_ld + k) = r;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
+    if (dx_max != nullptr) fold_absmax(vmax, dx_max);
 }
 
 // thread (row lane, column quad): K/4 quads side by side, 256 / (K/4) row lanes; partial sums meet in LDS
@@ -209,12 +217,12 @@ static bool enabled() {
 bool skinny_k_forward_ok(int N, int K) { return enabled() && K <= kSkinnyK && N >= 64; }
 
 int skinny_k_forward(const float *x, int64_t x_ld, const float *w, int64_t w_ld, const float *bias, float *y, int64_t y_ld,
-                     int M, int N, int K, int relu, hipStream_t s) {
+                     int M, int N, int K, int relu, float *y_max, hipStream_t s) {
     int rows_per_block = 64;
     while (ceil_div(M, rows_per_block) > 32768) rows_per_block *= 2;     // grid.y stays below the launch limit
     dim3 grid((unsigned)ceil_div(N, kSkThreads), (unsigned)ceil_div(M, rows_per_block));
     hipLaunchKernelGGL(skinny_k_fwd_kernel, grid, dim3(kSkThreads), 0, s, x, x_ld, w, w_ld, bias, y, y_ld, M, N, K, relu,
-                       rows_per_block);
+                       rows_per_block, y_max);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
@@ -253,10 +261,10 @@ int gemv_forward(const float *x, int64_t x_ld, const float *w, const float *bias
 }
 
 int gemv_backward_data(const float *dz, int64_t dz_ld, const float *w, float *dx, int64_t dx_ld, const float *mask,
-                       int64_t mask_ld, int M, int K, hipStream_t s) {
+                       int64_t mask_ld, int M, int K, float *dx_max, hipStream_t s) {
     const int64_t blocks = ceil_div((int64_t)M * (K / 4), kSkThreads);
     hipLaunchKernelGGL(gemv_bwd_data_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kSkThreads), 0, s, dz, dz_ld, w,
-                       dx, dx_ld, mask, mask_ld, M, K);
+                       dx, dx_ld, mask, mask_ld, M, K, dx_max);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
