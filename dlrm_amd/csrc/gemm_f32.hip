@@ -627,7 +627,9 @@ __device__ inline void interleave_half() {
 }
 
 template <bool A_RC, bool B_RC, int TM, int TN, int NP>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams p) {
+__global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_split_kernel(GemmParams p) {
+    // (f16 pieces: three workgroups per compute unit hide the LDS round trips of the forward and backward-data
+    //  products better than two -- 168 registers, a few spilled dwords; the weight gradient is faster with two)
     constexpr int MI = TM / 64, NI = TN / 64, PA = TM / 64, PB = TN / 64;
     constexpr int kStage = NP * plane_bytes(TM) + NP * plane_bytes(TN);   // A planes then B planes
     constexpr int kOutStaging = 4 * 32 * (32 * NI + 4) * 4;               // the epilogue parks accumulators here
