@@ -97,8 +97,17 @@ def test_fused_sgd_update_at_full_size(tables):
     w[uniq] = before                                                      # hand the tables back as they were
 
 
+@pytest.fixture(params=[1, 2], ids=["bf16x3", "f16x2"])
+def gemm_eval(request):
+    from dlrm_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(old)
+
+
 @pytest.mark.parametrize("N,K", [(1024, 1024), (1024, 479), (512, 13), (1, 256)])
-def test_layers_at_full_batch(N, K):
+def test_layers_at_full_batch(N, K, gemm_eval):
     from dlrm_amd import ops
     g = torch.Generator(device="cuda").manual_seed(N + K)
     ld = (K + 127) // 128 * 128 if K > 128 else (K + 3) // 4 * 4
@@ -111,7 +120,8 @@ def test_layers_at_full_batch(N, K):
     rows = torch.randint(0, B, (512,), generator=g, device="cuda")
     ref = torch.relu(x[rows].double() @ w.double().t() + b.double())
     assert (y[rows].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
-    # linearity of the product (no bias, no activation): f(2x) = 2 f(x) exactly (a power of two scales every term)
+    # linearity of the product (no bias, no activation): f(2x) = 2 f(x) exactly (a power of two scales every term; with
+    # f16 pieces it moves the operand's scale by the same power of two, so the pieces do not change at all)
     y1 = ops.linear_forward(x, w, None, False)
     y2 = ops.linear_forward(x * 2, w, None, False)
     assert torch.equal(y2, y1 * 2)
@@ -124,6 +134,40 @@ def test_layers_at_full_batch(N, K):
     dx = ops.linear_backward_data(dz, w)
     ref_dx = dz[rows].double() @ w.double()
     assert (dx[rows].double() - ref_dx).abs().max().item() <= 1e-5 * max(ref_dx.abs().max().item(), 1e-30)
+
+
+def test_c_hosted_train_step_is_reproducible_at_full_size():
+    """the step hosted in the library, big layers on f16 pieces (what a model of this batch size picks): same bar"""
+    from dlrm_amd.cmodel import CModel
+    from dlrm_amd.data import synthetic_batch
+    from dlrm_amd.model import DLRMConfig
+    cfg = DLRMConfig.mlperf(lr=1e-4)
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < sum(cfg.table_rows) * cfg.dim * 4 + (24 << 30):
+        pytest.skip("needs the 96 GB of tables plus work buffers in HBM")
+    dense, idx, off, labels = synthetic_batch(cfg.table_rows, B, cfg.lookups, cfg.dense_in, "cuda", seed=100, loss=cfg.loss,
+                                              local_batch=B)
+
+    def run():
+        m = CModel(cfg, B, seed=3, one_id_per_bag=True, idx_dtype=idx.dtype)
+        m.init_dense(5)
+        out = []
+        for s in range(3):
+            m.load_batch(dense.contiguous(), labels)
+            out.append(m.train_step(idx, off).item())
+        torch.cuda.synchronize()
+        assert int(m.err_flag.item()) == 0
+        sums = [m.weight[i::7919].double().sum().item() for i in range(3)]
+        params = m.params.clone()
+        m.close()
+        torch.cuda.empty_cache()
+        return out, sums, params
+
+    l1, s1, p1 = run()
+    l2, s2, p2 = run()
+    assert l1 == l2 and s1 == s2 and torch.equal(p1, p2)
+    assert all(np.isfinite(l1)) and l1[2] < l1[0]
 
 
 def test_train_step_is_reproducible_at_full_size():
