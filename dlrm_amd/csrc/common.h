@@ -108,6 +108,21 @@ __device__ inline void fold_absmax(float vmax, float *slot) {
         atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(vmax));
 }
 
+// The same for a whole 256-thread workgroup: one atomic per workgroup (kernels whose workgroups all finish at the same
+// moment would otherwise all find the slot still empty).  Every thread of the workgroup must call it.
+__device__ inline void fold_absmax_block(float vmax, float *slot) {
+    __shared__ float part[4];
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, k, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        vmax = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (__float_as_uint(vmax) > *reinterpret_cast<volatile unsigned *>(slot))
+            atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(vmax));
+    }
+}
+
 // power-of-two scale for an operand whose largest magnitude has the float32 bits `absmax_bits`: the scaled maximum
 // lands in [2^13, 2^14); zero / denormal maxima scale by 2^127, infinities and NaNs by 2^-115 (the product is then
 // whatever float32 arithmetic makes of them)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kSkThreads) void skinny_k_fwd_kernel(const float *_
             vmax = fmaxf(vmax, fabsf(a));
         }
     }
-    if (y_max != nullptr) fold_absmax(vmax, y_max);
+    if (y_max != nullptr) fold_absmax_block(vmax, y_max);
 }
 
 // the same walk with the roles swapped: dz[m][n] streams in (coalesced), x[m][:] comes from LDS, the thread keeps
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kSkThreads) void gemv_bwd_data_kernel(const float *
         *reinterpret_cast<float4 *>(dx + m * dx_ld + k) = r;
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
-    if (dx_max != nullptr) fold_absmax(vmax, dx_max);
+    if (dx_max != nullptr) fold_absmax_block(vmax, dx_max);
 }
 
 // thread (row lane, column quad): K/4 quads side by side, 256 / (K/4) row lanes; partial sums meet in LDS
@@ -263,7 +263,8 @@ int gemv_forward(const float *x, int64_t x_ld, const float *w, const float *bias
 int gemv_backward_data(const float *dz, int64_t dz_ld, const float *w, float *dx, int64_t dx_ld, const float *mask,
                        int64_t mask_ld, int M, int K, float *dx_max, hipStream_t s) {
     const int64_t blocks = ceil_div((int64_t)M * (K / 4), kSkThreads);
-    hipLaunchKernelGGL(gemv_bwd_data_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kSkThreads), 0, s, dz, dz_ld, w,
+    const int64_t cap = dx_max ? 2048 : 8192;     // (fewer, longer workgroups when each ends with an atomic)
+    hipLaunchKernelGGL(gemv_bwd_data_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(kSkThreads), 0, s, dz, dz_ld, w,
                        dx, dx_ld, mask, mask_ld, M, K, dx_max);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
