@@ -81,7 +81,9 @@ __device__ inline void split2_pair(f32x2 x, float scale, unsigned &h, unsigned &
     const f32x2 xs = x * scale;
     const f16x2 hh = __builtin_convertvector(xs, f16x2);
     h = __builtin_bit_cast(unsigned, hh);
-    const f32x2 r = xs - __builtin_convertvector(hh, f32x2);
+    // x * scale - h in one mixed-precision fma per element (v_fma_mix_f32 reads the f16 piece directly; the product
+    // with a power of two is exact, so this is the same value as xs - float(h))
+    const f32x2 r = {__builtin_fmaf(x[0], scale, -(float)hh[0]), __builtin_fmaf(x[1], scale, -(float)hh[1])};
     const f16x2 lh = __builtin_convertvector(r, f16x2);
     l = __builtin_bit_cast(unsigned, lh);
 }
