@@ -2,14 +2,19 @@
 // (x W^T + b, ReLU), backward-data (dz W, masked by the previous layer's ReLU) and backward-weight
 // (dz^T x, split over the batch dimension, partial slabs added in a fixed order).
 //
-// Operands and results are float32 in memory.  Two kernels evaluate the same product; the layer
-// descriptor's gemm_mode picks one:
-//   gemm_bf16x3_kernel (default)  every element is split exactly into three bf16 pieces when its tile goes
-//                                 from registers to LDS; six cross terms on v_mfma_f32_32x32x16_bf16 with
-//                                 float32 accumulation: float32 accuracy at 8/3 of the float32 matrix rate.
-//                                 Described in front of the kernel, further down.
-//   gemm_f32_kernel               v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit for bit a k-ordered
-//                                 fmaf chain.  Described next.
+// Operands and results are float32 in memory.  Two kernel templates evaluate the same product in three ways; the
+// layer descriptor's gemm_mode picks one:
+//   gemm_split_kernel<.., 3>      (DLRM_GEMM_BF16X3, the operators' default) every element is split exactly into
+//                                 three bf16 pieces when its tile goes from registers to LDS; six cross terms on
+//                                 v_mfma_f32_32x32x16_bf16 with float32 accumulation: float32 accuracy at 8/3 of
+//                                 the float32 matrix rate.  Described in front of the kernel, further down.
+//   gemm_split_kernel<.., 2>      (DLRM_GEMM_F16X2) two f16 pieces of every element times a power-of-two scale
+//                                 chosen from the operand's largest magnitude, three cross terms on
+//                                 v_mfma_f32_32x32x16_f16: half the matrix work, representation error about one
+//                                 float32 ulp per product.  The maxima come in through the descriptor (epilogues
+//                                 leave max |output| behind for the next layer) or from a pass of absmax_kernel.
+//   gemm_f32_kernel               (DLRM_GEMM_F32_MFMA) v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit for bit
+//                                 a k-ordered fmaf chain.  Described next.
 //
 // One kernel template covers the three products.  C[i][j] = sum_r A(i,r) B(j,r)
 // where each operand is addressed either with the reduction index contiguous
@@ -375,6 +380,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmParams p)
 //              out of the hardware transposing read ds_read_b64_tr_b16 (two per fragment)
 // 48 KB of LDS per workgroup at 128 x 128 (12 KB per 64 of R and operand); the register budget allows two
 // workgroups per CU.
+//
+// The same pipeline with NP = 2 planes per operand carries the f16x2 evaluation (common.h: split2_pair): 12 MFMAs per
+// half-step of a 128 x 128 tile instead of 24, 32 KB of LDS for the stages; the kernel is then bound by the LDS
+// traffic and the split arithmetic rather than by the matrix pipe.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
