@@ -191,10 +191,10 @@ int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_
  *      three leading cross terms run on v_mfma_f32_32x32x16_f16 with float32 accumulation and the result is scaled
  *      back.  The representation error is about one float32 ulp of each product (7.5e-8 relative rms, against a
  *      float64 product; the float32 accumulation of ANY of the modes, this one included, contributes 2e-7 to 4e-7 at
- *      reduction lengths of 512 to 65536), at half the matrix work of BF16X3: 1.4 to 1.65 times faster on the
+ *      reduction lengths of 512 to 65536), at half the matrix work of BF16X3: 1.3 to 1.6 times faster on the
  *      65536-row layers.  It needs max |x| of both operands before the kernel starts: handed in through the
  *      descriptor's *_absmax fields (a GEMM of this library can leave its output's maximum behind for the next
- *      one), else measured by a pass over the operand inside the call, which costs about what the mode gains.
+ *      one), else measured by a pass over the operand inside the call, which costs most of what the mode gains.
  *      dlrm_model_* uses it for the layers of models with a local batch of 8192 and above when its gemm_mode is
  *      DLRM_GEMM_DEFAULT.
  * The mode is a field of the layer descriptor: a recorded step (dlrm_plan) keeps the mode it was recorded
