@@ -236,8 +236,8 @@ def test_c_hosted_sharded_step_several_ranks_one_gpu(name, rw, world):
     assert dict(ret) == {r: True for r in range(world)}
 
 
-@pytest.mark.parametrize("one_id", [True, False])
-def test_c_hosted_graphed_steps_equal_direct_launches(one_id):
+@pytest.mark.parametrize("one_id,gemm", [(True, 0), (False, 0), (True, 3)], ids=["one-id", "bags", "one-id-f16x2"])
+def test_c_hosted_graphed_steps_equal_direct_launches(one_id, gemm):
     """graph_steps: the step's launches are captured per set of batch buffers and replayed.  Ten steps over three
     resident batches (so every graph is replayed at least twice) leave tables, dense parameters, predictions and loss
     bit-identical to the same steps launched directly; a NULL-stream caller falls back to direct launches."""
@@ -253,8 +253,8 @@ def test_c_hosted_graphed_steps_equal_direct_launches(one_id):
 
     def run(stream, **kw):
         with torch.cuda.stream(stream):
-            m = CModel(cfg, B, seed=1, one_id_per_bag=one_id, **kw)
-            m.init_dense(2)
+            m = CModel(cfg, B, seed=1, one_id_per_bag=one_id, gemm_mode=gemm, **kw)   # (3 = DLRM_GEMM_F16X2: the passes that
+            m.init_dense(2)                                                            #  measure operands are captured too)
             losses = []
             for i in range(10):
                 dense, idx, off, labels = batches[i % 3]
