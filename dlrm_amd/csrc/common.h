@@ -100,6 +100,13 @@ struct AbsmaxItem {
 };
 int absmax_many(const AbsmaxItem *items, int n, hipStream_t s);
 
+// dlrm_interact_dot_forward_gather / dlrm_interact_dot_backward with one more output (interact.hip): the largest
+// magnitude of the interaction's output / of feature 0's gradient, folded into a slot like the GEMM epilogues do
+int interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,
+                                    float *d_x_copy, float *d_out_max, dlrm_stream_t stream);
+int interact_dot_backward_max(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F, int32_t D,
+                              float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max, dlrm_stream_t stream);
+
 // Folds the largest magnitude a wave has seen (per-lane `vmax` >= 0) into *slot: one wave reduction, at most one atomic
 // per wave and only if it can still raise the slot (thousands of atomics on one address queue up behind each other;
 // a stale read costs one atomic too many, never a wrong result).  Every lane of the wave must call it.

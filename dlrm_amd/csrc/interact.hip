@@ -80,8 +80,9 @@ __device__ inline void sample_park(float *__restrict__ sx, const int (&lds_off)[
 
 // Z = X X^T of the sample staged at sx ([32][ld], rows F.. zero) and the sample's output row: the dense copy of
 // feature 0, the strict lower triangle of Z, zeros up to out_ld
+// (vmax: running maximum of the magnitudes this lane has stored into output rows, for callers that want max |out|)
 __device__ inline void fwd_sample(const float *__restrict__ sx, int F, int D, int ld, float *__restrict__ o, int64_t out_ld,
-                                  int lane) {
+                                  int lane, float &vmax) {
     const int row = lane & 31, h = lane >> 5;
     const int n_pairs = F * (F - 1) / 2;
     f32x16 acc;
@@ -106,13 +107,20 @@ __device__ inline void fwd_sample(const float *__restrict__ sx, int F, int D, in
         }
     }
     // dense copy (feature 0) and zero padding of the row tail
-    for (int d = lane; d < D; d += 64) o[d] = sx[d];
+    for (int d = lane; d < D; d += 64) {
+        const float v = sx[d];
+        o[d] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+    }
     for (int64_t c = D + n_pairs + lane; c < out_ld; c += 64) o[c] = 0.f;
     // register r of lane l holds Z[i][j], i = (r&3) + 8*(r>>2) + 4*h, j = l&31
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (i < F && row < i) o[D + i * (i - 1) / 2 + row] = acc[r];
+        if (i < F && row < i) {
+            o[D + i * (i - 1) / 2 + row] = acc[r];
+            vmax = fmaxf(vmax, fabsf(acc[r]));
+        }
     }
 }
 
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
         // next sample's loads fly behind the MFMAs (the last iteration re-reads its own sample)
         sample_fetch<NV>(x + (b + stride < B ? b + stride : b) * F * D, last_idx, lane, pre);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane);
+        float unused = 0.f;
+        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane, unused);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -152,7 +161,8 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_fwd_kernel(const flo
 template <int NV>
 __device__ inline void bwd_sample(float *__restrict__ sx, const float *__restrict__ ss, int F, int D, int ld,
                                   const float *__restrict__ go, float *__restrict__ gx, const int (&lds_off)[NV], int last_idx,
-                                  int relu_mask0, int lane) {
+                                  int relu_mask0, int lane, float &vmax0) {
+    // (vmax0: running maximum of the magnitudes of feature 0's gradient, the bottom MLP's incoming gradient)
     const int row = lane & 31, h = lane >> 5;
     // A operand S' = S + S^T (rows = output feature, reduction over the other feature, 32 deep = two steps of 16):
     // lane (row, h) holds elements 16s + 8h .. + 7 of its row, as three bf16 pieces (float32 products on the bf16
@@ -194,6 +204,7 @@ __device__ inline void bwd_sample(float *__restrict__ sx, const float *__restric
                 if (i == 0) {
                     v += go[d];
                     if (relu_mask0 && !(sx[d] > 0.f)) v = 0.f;
+                    vmax0 = fmaxf(vmax0, fabsf(v));
                 }
                 sx[i * ld + d] = v;
             }
@@ -213,10 +224,12 @@ template <int NV>
 __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const float *__restrict__ x,
                                                                         const float *__restrict__ dout,
                                                                         int64_t dout_ld, int64_t B, int F, int D,
-                                                                        float *__restrict__ dx, int relu_mask0) {
+                                                                        float *__restrict__ dx, int relu_mask0,
+                                                                        float *__restrict__ dx0_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = D + 4;
+    float vmax0 = 0.f;
     // per wave: the sample [F][ld] and the gradient tile [F][kSLd] (+ one spare cell); only F rows
     // are kept (operand rows F..31 are masked at the reads), which lets two workgroups share a CU
     float *sx = smem + (size_t)wave * (F * ld + F * kSLd + 4);
@@ -277,9 +290,10 @@ __global__ __launch_bounds__(kIntThreads) void interact_dot_bwd_kernel(const flo
             fetch_grad(nb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, dx + b * F * D, lds_off, last_idx, relu_mask0, lane);
+        bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, dx + b * F * D, lds_off, last_idx, relu_mask0, lane, vmax0);
         __builtin_amdgcn_wave_barrier();
     }
+    if (dx0_max != nullptr) fold_absmax_block(vmax0, dx0_max);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -373,10 +387,12 @@ __device__ inline void gather_park(float *__restrict__ sx, int n4, int D, int ld
 template <int NV, typename IdxT>
 __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_gather_kernel(GatherArgs g, int64_t B, int F, int D,
                                                                                float *__restrict__ out, int64_t out_ld,
-                                                                               float *__restrict__ x_copy) {
+                                                                               float *__restrict__ x_copy,
+                                                                               float *__restrict__ out_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = D + 4;
+    float vmax = 0.f;
     float *sx = smem + (size_t)wave * kFP * ld;
     int *sidx = reinterpret_cast<int *>(smem + (size_t)kIntWaves * kFP * ld);
     for (int i = lane; i < (kFP - F) * ld; i += 64) sx[F * ld + i] = 0.f;   // rows F..31 stay zero
@@ -404,10 +420,11 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_gather_kernel
                 gather_fetch<NV>(g, sidx, jn, b0 + jn, n4, D, ld, lane, pre);
             }
             __builtin_amdgcn_sched_barrier(0);
-            fwd_sample(sx, F, D, ld, out + (b0 + j) * out_ld, out_ld, lane);
+            fwd_sample(sx, F, D, ld, out + (b0 + j) * out_ld, out_ld, lane, vmax);
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (out_max != nullptr) fold_absmax_block(vmax, out_max);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -455,7 +472,8 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_views_kernel(
         __builtin_amdgcn_wave_barrier();
         views_fetch<NV>(sb, sst, b + stride < B ? b + stride : b, n4, D, ld, lane, pre);
         __builtin_amdgcn_sched_barrier(0);
-        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane);
+        float unused = 0.f;
+        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane, unused);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -526,7 +544,8 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_views_kernel(
             int lds_off[NV];   // (unused by a bwd_sample that leaves the store to its caller)
 #pragma unroll
             for (int u = 0; u < NV; u++) lds_off[u] = 0;
-            bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane);
+            float unused = 0.f;
+            bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane, unused);
         }
         {   // every feature's gradient to its own place
             const int lv = opaque(lane);
@@ -582,6 +601,13 @@ extern "C" int dlrm_interact_dot_forward(const float *d_x, int64_t B, int32_t F,
 extern "C" int dlrm_interact_dot_backward(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B,
                                           int32_t F, int32_t D, float *d_dx, int32_t relu_mask_feature0,
                                           dlrm_stream_t stream) {
+    return dlrm::interact_dot_backward_max(d_x, d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0, nullptr, stream);
+}
+
+// the same launch; d_dx0_max (or NULL): max |gradient of feature 0| is folded into it (the hosted model's bottom MLP
+// takes that gradient as an operand of its f16x2 products)
+int dlrm::interact_dot_backward_max(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F, int32_t D,
+                                    float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max, dlrm_stream_t stream) {
     if (int rc = check_interact(d_x, B, F, D)) return rc;
     if (B == 0) return DLRM_OK;
     DLRM_REQUIRE(d_dout != nullptr && d_dx != nullptr && dout_ld >= D + F * (F - 1) / 2,
@@ -596,7 +622,7 @@ extern "C" int dlrm_interact_dot_backward(const float *d_x, const float *d_dout,
         DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_kernel<NV>),                   \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hipLaunchKernelGGL(interact_dot_bwd_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), d_x, \
-                           d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0);                                     \
+                           d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0, d_dx0_max);                          \
         break;
     switch (nv) {
         DLRM_INT_BWD(1) DLRM_INT_BWD(2) DLRM_INT_BWD(3) DLRM_INT_BWD(4) DLRM_INT_BWD(5) DLRM_INT_BWD(6) DLRM_INT_BWD(7)
@@ -633,6 +659,12 @@ static int check_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, 
 
 extern "C" int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out,
                                                 int64_t out_ld, float *d_x_copy, dlrm_stream_t stream) {
+    return dlrm::interact_dot_forward_gather_max(e, d_x0, x0_ld, d_out, out_ld, d_x_copy, nullptr, stream);
+}
+
+// the same launch; d_out_max (or NULL): max |out| is folded into it
+int dlrm::interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,
+                                          float *d_x_copy, float *d_out_max, dlrm_stream_t stream) {
     GatherArgs g{};
     if (int rc = check_gather(e, d_x0, x0_ld, &g)) return rc;
     const int64_t B = e->batch;
@@ -651,12 +683,12 @@ extern "C" int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const floa
             DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_gather_kernel<NV, int64_t>),  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
             hipLaunchKernelGGL((interact_dot_fwd_gather_kernel<NV, int64_t>), dim3(blocks), dim3(kIntThreads), lds,    \
-                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy);                                \
+                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy, d_out_max);                     \
         } else {                                                                                                       \
             DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_gather_kernel<NV, int32_t>),  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
             hipLaunchKernelGGL((interact_dot_fwd_gather_kernel<NV, int32_t>), dim3(blocks), dim3(kIntThreads), lds,    \
-                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy);                                \
+                               as_stream(stream), g, B, F, D, d_out, out_ld, d_x_copy, d_out_max);                     \
         }                                                                                                              \
         break;
     switch (nv) {

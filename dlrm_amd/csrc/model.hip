@@ -402,8 +402,9 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
         dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
         if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
                 // (a training step whose backward pass reads the block gets it written in place around feature 0)
-                return dlrm_interact_dot_forward_gather(&e, m->feat, m->feat_ld, m->inter, m->inter_ld,
-                                                        train ? m->feat : nullptr, main);
+                float *out_max = big_layer(m, m->topl[0]) ? out_slot(m, m->topl[0].s_x) : nullptr;
+                return interact_dot_forward_gather_max(&e, m->feat, m->feat_ld, m->inter, m->inter_ld,
+                                                       train ? m->feat : nullptr, out_max, main);
             }))
             return rc;
     } else {
@@ -879,7 +880,8 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
                 if (m->views)   // gradients straight into the send blocks of the backward exchange
                     return dlrm_interact_dot_backward_views(m->x_views.data(), m->dinter, m->inter_ld, m->B, m->F, m->D,
                                                             m->dx_views.data(), 1, main);
-                return dlrm_interact_dot_backward(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, main);
+                float *dx0_max = big_layer(m, m->bot.back()) ? out_slot(m, m->bot.back().s_dz) : nullptr;
+                return interact_dot_backward_max(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, dx0_max, main);
             }))
             return rc;
     } else {
