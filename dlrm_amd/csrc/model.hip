@@ -525,8 +525,10 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
 
     // ---- streams and events
     // (single GPU: the sparse update beside the bottom MLP's backward pass -- an HBM-bound kernel beside matrix-bound
-    //  ones: local batch 8192 and 16384 +2.6 %, 65536 +1.2 %; Criteo-Kaggle's 2048 -5 %, so not below 8192)
-    if (c->overlap < 0 ? (sharded || c->local_batch >= 8192) : c->overlap != 0)
+    //  ones: local batch 8192 and 16384 +2.6 %; Criteo-Kaggle's 2048 -5 %, so not below 8192; 65536 +1.2 %, not taken
+    //  by default: the kernels that share the chip then take 15-25 % longer each and per-operator times stop
+    //  describing the operators)
+    if (c->overlap < 0 ? (sharded || (c->local_batch >= 8192 && c->local_batch <= 32768)) : c->overlap != 0)
         if (hipStreamCreateWithFlags(&m->s_emb, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
     m->cfg.presort = c->presort != 0;
     if (m->cfg.presort)

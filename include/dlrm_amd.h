@@ -764,7 +764,7 @@ typedef struct dlrm_model_config {
     const int32_t *table_owner;  /* host int32[T]: owning rank, -1 = split by rows; NULL = whole tables placed */
                                  /* greedily (biggest first, to the rank with the fewest tables, then bytes) */
     int32_t force_exchange;      /* run the sharded schedule (every exchange, with one peer) even when world == 1 */
-    int32_t overlap;             /* embedding side on its own stream: 1 / 0, -1 = when sharded or local_batch >= 8192 */
+    int32_t overlap;             /* embedding side on its own stream: 1 / 0, -1 = when sharded or 8192 <= local_batch <= 32768 */
     int32_t presort;             /* sort the sparse update's occurrences beside the forward pass (own stream) */
     int32_t wgrad_stream;        /* weight gradients on their own stream: 1 / 0, -1 = when local_batch <= 32768 */
     uint64_t seed;               /* tables: uniform [0,1), table t seeded (seed << 20) + 7919 (t + 1) */
