@@ -72,7 +72,7 @@ __device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &
 
 // Two-piece split on the f16 matrix pipe: xs = x * scale with scale a power of two that puts the operand's largest
 // magnitude just below 2^14 (so h cannot overflow f16), h = f16(xs), l = f16(xs - h).  h + l carries 22 mantissa bits of
-// every element within 2^11 of the largest and at least 2^-38 of the largest magnitude in absolute terms for the rest;
+// every element within 2^15 of the largest and at least 2^-38 of the largest magnitude in absolute terms for the rest;
 // the three leading cross terms hh + hl + lh with float32 accumulation leave a representation error near one float32
 // ulp (measured 7.5e-8 relative rms against float64, below the accumulation error of any float32 GEMM).
 // a pair of float32 -> the pair's two f16 pieces (each packed in one dword), 8 VALU operations
