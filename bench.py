@@ -450,6 +450,33 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         infer = {"samples_per_s": Bg * n_inf / dt_inf, "ms_per_batch": dt_inf * 1e3 / n_inf, "batches": n_inf,
                  "launch": "dlrm_model_forward"}
 
+    # The same steps with the layers' products on bf16 pieces -- the evaluation whose split of the operands is exact
+    # (24 mantissa bits) -- measured in the same process right behind the run above, so that the line carries both.
+    exact_ref = None
+    if world == 1 and gemm == "f16x2" and not args.no_exact_reference and not args.graph:
+        model.close()
+        model = CModel(cfg, B, rank=rank, world=world, comm=cm, table_owner=owner, seed=0,
+                       overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
+                       wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
+                       gemm_mode=GEMM_CHOICES["bf16x3"][0], one_id_per_bag=gather, force_exchange=args.force_exchange)
+        model.init_dense(0)
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            ref_loss = step(args.warmup + i)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        exact_ref = {"gemm": GEMM_CHOICES["bf16x3"][5], "value": Bg * args.steps / dt2, "unit": "samples/s",
+                     "ms_per_step": dt2 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup,
+                     "loss": float(ref_loss.item()),
+                     "note": "same model, batches, stream options and step count, no operator timing inside the steps.  The "
+                             "two losses are not a parity check: with the reference's unscaled N(0,1) layer weights this "
+                             "synthetic run is ill-conditioned (the loss of step 1 is in the hundreds) and runs that differ "
+                             "in the last bit drift apart within a few steps -- the float32 MFMA evaluation ends at yet "
+                             "another value; parity is what tests/ measure, per operator and per step against the oracle"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(cfg)
@@ -475,7 +502,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
             "loss": loss_value, "cache": None, "inference": infer, "roofline": roofline,
             "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3, "embbag_hbm_gbps_from": emb_note,
             "kernels": kernels, "kernels_timed": "every class, in %d extra steps after the timed region" % n_k,
-            "cpu_baseline": cpu_baseline,
+            "cpu_baseline": cpu_baseline, "exact_split_reference": exact_ref,
         }
         print(json.dumps(line))
     model.close()
@@ -531,6 +558,11 @@ def main():
     ap.add_argument("--no-presort", action="store_true", help="sort the occurrences inside the sparse update")
     ap.add_argument("--gemm", default="auto", choices=["auto", "f32", "bf16x3", "f16x2"],
                     help="evaluation of the big layers' float32 products (auto: f16x2 from a local batch of 8192 up, else bf16x3)")
+    ap.add_argument("--lr", type=float, default=0.0,
+                    help="learning rate (default: the configuration's, 0.01 like the reference's SGD; on random labels "
+                         "that run is chaotic and the loss after a few steps says nothing, a small rate keeps it smooth)")
+    ap.add_argument("--no-exact-reference", action="store_true",
+                    help="skip the second, shorter measurement of the same steps on bf16 pieces (f16x2 runs only)")
     ap.add_argument("--wgrad-stream", default="auto", choices=["auto", "on", "off"],
                     help="MLP weight gradients on their own stream beside the data gradients (auto: local batch <= 32768)")
     ap.add_argument("--progress", action="store_true", help="synchronise and print a line to stderr after every step")
@@ -569,6 +601,8 @@ def main():
     from dlrm_amd.model import DLRM, DLRMConfig
 
     cfg = DLRMConfig.mlperf() if args.config == "mlperf" else DLRMConfig.kaggle()
+    if args.lr > 0:
+        cfg.lr = args.lr
     if args.row_cap:
         cfg.table_rows = [min(r, args.row_cap) for r in cfg.table_rows]
     Bg = args.global_batch

@@ -42,15 +42,15 @@ for w in $WHAT; do
       pmc cache_vec WRITE_SIZE $A
       ;;
     kaggle)
-      trace kaggle python3 $ROOT/bench.py --config kaggle --steps 20 --warmup 3 --no-cpu-baseline
+      trace kaggle python3 $ROOT/bench.py --config kaggle --steps 20 --warmup 3 --no-cpu-baseline --no-exact-reference
       ;;
     b8192)
-      trace b8192 python3 $ROOT/bench.py --global-batch 8192 --steps 20 --warmup 3 --no-cpu-baseline
+      trace b8192 python3 $ROOT/bench.py --global-batch 8192 --steps 20 --warmup 3 --no-cpu-baseline --no-exact-reference
       ;;
     bench)
-      trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline
-      pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference
-      pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference
+      trace bench python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-reference
+      pmc bench FETCH_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-reference --no-inference
+      pmc bench WRITE_SIZE python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-reference --no-inference
       # (bench.py also launches operators outside the train steps -- the EmbeddingBag kernel on its own when the
       # step reads the rows inside the interaction kernel: per-launch averages only)
       python3 $ROOT/tools/traffic_from_pmc.py "$OUT/bench_FETCH_SIZE_pmc.json" "$OUT/bench_WRITE_SIZE_pmc.json" 0 \
@@ -59,9 +59,9 @@ for w in $WHAT; do
     mfma)   # matrix-pipe busy cycles of the GEMM kernels in the step, at both batch sizes, and where their waves wait
       M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE"
       W="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-      pmc mfma_b65536 "$M" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-      pmc mfma_b8192 "$M" python3 $ROOT/bench.py --global-batch 8192 --steps 2 --warmup 1 --no-cpu-baseline
-      pmc wait_b65536 "$W" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+      pmc mfma_b65536 "$M" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-reference
+      pmc mfma_b8192 "$M" python3 $ROOT/bench.py --global-batch 8192 --steps 2 --warmup 1 --no-cpu-baseline --no-exact-reference
+      pmc wait_b65536 "$W" python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-reference
       ;;
   esac
 done
