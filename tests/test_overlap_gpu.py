@@ -14,8 +14,18 @@ ROWS = [1460, 583, 1000000, 200000, 305, 24, 12517, 633, 3, 93145, 5683, 800000,
         4, 700000, 18, 15, 286181, 105, 142572]
 
 
-def test_sparse_update_beside_weight_gradients_equals_the_serial_run():
+@pytest.mark.parametrize("gemm", [1, 2], ids=["bf16x3", "f16x2"])
+def test_sparse_update_beside_weight_gradients_equals_the_serial_run(gemm):
     from dlrm_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(gemm)
+    try:
+        _update_beside_weight_gradients(ops)
+    finally:
+        ops.set_gemm_mode(old)
+
+
+def _update_beside_weight_gradients(ops):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(5)
     B, T, D = 2048, len(ROWS), 16
