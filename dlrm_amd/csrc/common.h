@@ -71,19 +71,24 @@ __device__ inline void split3_pair(f32x2 x, unsigned &h, unsigned &m, unsigned &
 }
 
 // Two-piece split on the f16 matrix pipe: xs = x * scale with scale a power of two that puts the operand's largest
-// magnitude just below 2^14 (so h cannot overflow f16), h = f16(xs), l = f16(xs - h).  h + l carries 22 mantissa bits of
-// every element within 2^15 of the largest and at least 2^-38 of the largest magnitude in absolute terms for the rest;
-// the three leading cross terms hh + hl + lh with float32 accumulation leave a representation error near one float32
-// ulp (measured 7.5e-8 relative rms against float64, below the accumulation error of any float32 GEMM).
-// a pair of float32 -> the pair's two f16 pieces (each packed in one dword), 8 VALU operations
+// magnitude into [2^13, 2^14) (so h cannot overflow f16), h = f16(xs), l = f16((xs - h) * 2^11): the low piece is kept
+// 2^11 times too large, so that it stays a normal f16 number for every |xs| >= 2^-14.  h + l * 2^-11 then carries 22
+// mantissa bits of every element within 2^27 of the operand's largest (without the factor: within 2^15), and an absolute
+// error of at most 2^-49 of the largest magnitude for the rest (f16 subnormals).  The product is h_a h_b in one
+// accumulator and h_a l_b + l_a h_b in a second one that enters the result times 2^-11; |l| <= 2^13, nothing overflows.
+// Representation error near one float32 ulp (7.5e-8 relative rms against float64, below the accumulation error of any
+// float32 GEMM).
+constexpr float kSplit2LowScale = 2048.f, kSplit2LowInv = 1.f / 2048.f;
+// a pair of float32 -> the pair's two f16 pieces (each packed in one dword)
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ inline void split2_pair(f32x2 x, float scale, unsigned &h, unsigned &l) {
     const f32x2 xs = x * scale;
     const f16x2 hh = __builtin_convertvector(xs, f16x2);
     h = __builtin_bit_cast(unsigned, hh);
     // x * scale - h in one mixed-precision fma per element (v_fma_mix_f32 reads the f16 piece directly; the product
-    // with a power of two is exact, so this is the same value as xs - float(h))
-    const f32x2 r = {__builtin_fmaf(x[0], scale, -(float)hh[0]), __builtin_fmaf(x[1], scale, -(float)hh[1])};
+    // with a power of two is exact and so is the difference: h holds the leading bits of xs)
+    const f32x2 r = {__builtin_fmaf(x[0], scale, -(float)hh[0]) * kSplit2LowScale,
+                     __builtin_fmaf(x[1], scale, -(float)hh[1]) * kSplit2LowScale};
     const f16x2 lh = __builtin_convertvector(r, f16x2);
     l = __builtin_bit_cast(unsigned, lh);
 }

@@ -594,23 +594,30 @@ __device__ inline void load_frags(const unsigned char *__restrict__ stage, int w
             }
 }
 
-// the cross terms for each of the wave's 32x32 accumulators, smallest terms first
+// the cross terms for each of the wave's 32x32 accumulators, smallest terms first.  Two f16 pieces: the low pieces are
+// stored 2^11 times too large (common.h: split2_pair), so the two mixed terms go to their own accumulator `lo`, which
+// the epilogue adds times 2^-11.
 template <int MI, int NI, int NP>
-__device__ inline void mfma_frags(const Frags<MI, NI, NP> &f, f32x16 (&acc)[MI][NI]) {
+__device__ inline void mfma_frags(const Frags<MI, NI, NP> &f, f32x16 (&acc)[MI][NI], f32x16 (&lo)[MI][NI]) {
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            f32x16 c = acc[mi][ni];
+            if constexpr (NP == 3) {
+                f32x16 c = acc[mi][ni];
 #pragma unroll
-            for (int t = 0; t < n_terms<NP>(); t++) {
-                if constexpr (NP == 3)
+                for (int t = 0; t < n_terms<NP>(); t++)
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][term_a<NP>(t)], f.b[ni][term_b<NP>(t)], c, 0, 0, 0);
-                else
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[mi][term_a<NP>(t)]),
-                                                               __builtin_bit_cast(f16x8, f.b[ni][term_b<NP>(t)]), c, 0, 0, 0);
+                acc[mi][ni] = c;
+            } else {
+                const f16x8 ah = __builtin_bit_cast(f16x8, f.a[mi][0]), al = __builtin_bit_cast(f16x8, f.a[mi][1]);
+                const f16x8 bh = __builtin_bit_cast(f16x8, f.b[ni][0]), bl = __builtin_bit_cast(f16x8, f.b[ni][1]);
+                f32x16 c = lo[mi][ni];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+                lo[mi][ni] = c;
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mi][ni], 0, 0, 0);
             }
-            acc[mi][ni] = c;
         }
 }
 
@@ -620,7 +627,7 @@ __device__ inline void mfma_frags(const Frags<MI, NI, NP> &f, f32x16 (&acc)[MI][
 // (128 x 128: three split operations behind every MFMA.)
 template <int I, int MI, int NI, int NP>
 __device__ inline void interleave_from() {
-    constexpr int kMfma = n_terms<NP>() * MI * NI, kValu = (NP == 3 ? 18 : 16) * (MI + NI), kWrites = (NP * (MI + NI)) / 4;
+    constexpr int kMfma = n_terms<NP>() * MI * NI, kValu = (NP == 3 ? 18 : 20) * (MI + NI), kWrites = (NP * (MI + NI)) / 4;
     if constexpr (I < kMfma) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, (kValu * (I + 1)) / kMfma - (kValu * I) / kMfma, 0);
@@ -636,13 +643,13 @@ __device__ inline void interleave_half() {
 }
 
 template <bool A_RC, bool B_RC, int TM, int TN, int NP>
-__global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_split_kernel(GemmParams p) {
-    // (f16 pieces: three workgroups per compute unit hide the LDS round trips of the forward and backward-data
-    //  products better than two -- 168 registers, a few spilled dwords; the weight gradient is faster with two)
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams p) {
     constexpr int MI = TM / 64, NI = TN / 64, PA = TM / 64, PB = TN / 64;
     constexpr int kStage = NP * plane_bytes(TM) + NP * plane_bytes(TN);   // A planes then B planes
     constexpr int kOutStaging = 4 * 32 * (32 * NI + 4) * 4;               // the epilogue parks accumulators here
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStage > kOutStaging ? 2 * kStage : kOutStaging];
+    constexpr int kStages = 2 * kStage > kOutStaging ? 2 * kStage : kOutStaging;
+    constexpr int kColsum = A_RC ? 0 : kGemmThreads * 16;                   // running bias-gradient sums, one f32x4 per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kStages + kColsum];
     unsigned char *const s0 = smem, *const s1 = smem + kStage;
     // f16 pieces: power-of-two scales from the operands' largest magnitudes (wave-uniform scalars)
     float scale_a = 1.f, scale_b = 1.f;
@@ -664,13 +671,13 @@ __global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_
     const int steps = (k_end - k_begin + BK - 1) / BK;
     const int full_steps = (k_end - k_begin) / BK;
 
-    f32x16 acc[MI][NI];
+    f32x16 acc[MI][NI], acc_lo[MI][NI];   // (acc_lo: the mixed terms of the f16 pieces; unused with bf16 pieces)
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.f;
+            for (int r = 0; r < 16; r++) { acc[mi][ni][r] = 0.f; acc_lo[mi][ni][r] = 0.f; }
 
     // (a_vec / b_vec: 16-byte aligned rows, so the leading dimensions are multiples of 4 elements; edge tiles of a
     // reduction-strided operand read whole pieces up to the leading dimension, see make_tile_addr)
@@ -678,17 +685,23 @@ __global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_
 
     // bias gradient (weight-gradient product only): this thread's four output rows of the A tile,
     // summed over every staged reduction row
+    // (the running sums live in LDS, one slot per thread that only this thread touches: four registers fewer in a
+    //  loop that is at the register limit with the two accumulator sets of the f16 pieces)
     const bool do_colsum = !A_RC && p.colsum != nullptr && bx == 0;
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 *const cs_slot = reinterpret_cast<f32x4 *>(smem + kStages) + threadIdx.x;
+    if constexpr (!A_RC) *cs_slot = f32x4{0.f, 0.f, 0.f, 0.f};
     // split half-step h of a raw tile pair into `stage` (`live` false: the registers hold no new
     // tile and the stage is never read; only the bias-gradient sum must skip them)
     auto stage_half = [&](unsigned char *stage, f32x4 (&xa)[2 * PA], f32x4 (&xb)[2 * PB], int h, bool live) {
         if constexpr (!A_RC) {
-            if (do_colsum) {
-                f32x4 add = xa[h * PA];
+            if (do_colsum && live) {
+                // LDS adds without return straight from the staged registers (one thread per slot: fixed order)
+                float *c = reinterpret_cast<float *>(cs_slot);
 #pragma unroll
-                for (int v = 1; v < PA; v++) add += xa[h * PA + v];
-                cs += live ? add : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int v = 0; v < PA; v++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        __hip_atomic_fetch_add(c + q, xa[h * PA + v][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         split_store_half<A_RC, TM, NP>(stage, &xa[h * PA], scale_a);
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_
             pin(ua, ub, 1);
             if constexpr (MASK) { mask_tail(&ua[PA], PA, k_begin + tt * BK, 1); mask_tail(&ub[PB], PB, k_begin + tt * BK, 1); }
             stage_half(s1, ua, ub, 1, true);
-            mfma_frags<MI, NI, NP>(f, acc);
+            mfma_frags<MI, NI, NP>(f, acc, acc_lo);
             interleave_half<MI, NI, NP>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_
                 mask_tail(&va[0], PA, k_begin + tn * BK, 0); mask_tail(&vb[0], PB, k_begin + tn * BK, 0);
             }
             stage_half(s0, va, vb, 0, tt + 1 < t_end);
-            mfma_frags<MI, NI, NP>(f, acc);
+            mfma_frags<MI, NI, NP>(f, acc, acc_lo);
             interleave_half<MI, NI, NP>();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
@@ -785,20 +798,22 @@ __global__ __launch_bounds__(kGemmThreads, (NP == 2 && A_RC) ? 3 : 2) void gemm_
     }
     if (t_done < steps) run(std::false_type{}, std::false_type{}, t_done, steps);   // edge tiles, unaligned operands
 
-    if constexpr (NP == 2) {      // undo the operand scales (two exact multiplications: either factor alone stays in range)
+    if constexpr (NP == 2) {      // mixed terms in, operand scales out (two exact multiplications: either factor alone stays in range)
         const float inv_a = 1.0f / scale_a, inv_b = 1.0f / scale_b;
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[mi][ni][r] = (acc[mi][ni][r] * inv_a) * inv_b;
+                for (int r = 0; r < 16; r++)
+                    acc[mi][ni][r] = (__builtin_fmaf(acc_lo[mi][ni][r], kSplit2LowInv, acc[mi][ni][r]) * inv_a) * inv_b;
     }
     float *fsm = reinterpret_cast<float *>(smem);
     if constexpr (!A_RC) {
         if (do_colsum) {
             // thread (tid / (TM/4), tid % (TM/4)) holds the sums of output rows 4 (tid % (TM/4)).. over its reduction rows
             constexpr int LPR = TM / 4, GROUPS = 256 / LPR;
+            const f32x4 cs = *cs_slot;
             *reinterpret_cast<f32x4 *>(fsm + (tid / LPR) * TM + (tid % LPR) * 4) = cs;
             __syncthreads();
             if (tid < TM && m0 + tid < p.M) {
