@@ -110,6 +110,8 @@ public:
         pool_ = static_cast<float *>(pool);
         ids_dev_.resize(table_num);
         rows_dev_.resize(table_num);
+        read_base_.assign(table_num, 0);
+        write_base_.assign(table_num, 0);
     }
     ~cache() {
         (void)hipDeviceSynchronize();
@@ -212,7 +214,7 @@ private:
     int64_t pool_rows_ = 0;
     std::vector<DeviceArray<int>> ids_dev_, rows_dev_;
     std::vector<int64_t> last_;
-    std::vector<int64_t> read_base_ = std::vector<int64_t>(64, 0), write_base_ = std::vector<int64_t>(64, 0);
+    std::vector<int64_t> read_base_, write_base_;   // [table] counter values at the last read_page / write_page
 };
 
 // reclaim_emb_cache (src/dlrmtest.cpp:397-412): evict down to cache_size, log the write counters
@@ -252,6 +254,8 @@ public:
         pool_ = static_cast<float *>(pool);
         ids_dev_.resize(table_num);
         rows_dev_.resize(table_num);
+        read_base_.assign(table_num, 0);
+        write_base_.assign(table_num, 0);
     }
     ~cache2() {
         (void)hipDeviceSynchronize();
@@ -365,7 +369,7 @@ private:
     int64_t pool_rows_ = 0;
     std::vector<DeviceArray<int>> ids_dev_, rows_dev_;
     std::vector<int64_t> last_;
-    std::vector<int64_t> read_base_ = std::vector<int64_t>(64, 0), write_base_ = std::vector<int64_t>(64, 0);
+    std::vector<int64_t> read_base_, write_base_;   // [table] counter values at the last read_page / write_page
 };
 
 // reclaim_emb_cache (src/dlrmtest2.cpp:462-481)

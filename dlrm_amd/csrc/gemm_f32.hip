@@ -694,15 +694,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams 
     // tile and the stage is never read; only the bias-gradient sum must skip them)
     auto stage_half = [&](unsigned char *stage, f32x4 (&xa)[2 * PA], f32x4 (&xb)[2 * PB], int h, bool live) {
         if constexpr (!A_RC) {
-            if (do_colsum && live) {
-                // LDS adds without return straight from the staged registers (one thread per slot: fixed order)
-                float *c = reinterpret_cast<float *>(cs_slot);
+            // (no branch: control flow inside a half-step would cut the region the scheduling recipe describes)
+            f32x4 add = xa[h * PA];
 #pragma unroll
-                for (int v = 0; v < PA; v++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        __hip_atomic_fetch_add(c + q, xa[h * PA + v][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            for (int v = 1; v < PA; v++) add += xa[h * PA + v];
+            *cs_slot += (do_colsum && live) ? add : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         split_store_half<A_RC, TM, NP>(stage, &xa[h * PA], scale_a);
         split_store_half<B_RC, TN, NP>(stage + NP * plane_bytes(TM), &xb[h * PB], scale_b);
@@ -1023,20 +1019,20 @@ int absmax_many(const AbsmaxItem *items, int n, hipStream_t s) {
 // captured with: hosts that replay graphs beside direct launches pass their own slots in the descriptors).
 constexpr unsigned kMaxRing = 8192;
 static __device__ unsigned g_max_ring[2 * kMaxRing];
-static void *g_max_ring_ptr[64];
+static std::atomic<void *> g_max_ring_ptr[64];   // (two host threads may ask at once: both find the same address)
 static std::atomic<unsigned> g_max_ring_next{0};
 
 static int ring_pair(float **out) {
     int dev = -1;
     DLRM_HIP(hipGetDevice(&dev));
     DLRM_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d outside 0..63", dev);
-    if (g_max_ring_ptr[dev] == nullptr) {
-        void *q = nullptr;
+    void *q = g_max_ring_ptr[dev].load(std::memory_order_acquire);
+    if (q == nullptr) {
         DLRM_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(g_max_ring)));
         DLRM_REQUIRE(q != nullptr, "hipGetSymbolAddress returned NULL");
-        g_max_ring_ptr[dev] = q;
+        g_max_ring_ptr[dev].store(q, std::memory_order_release);
     }
-    *out = static_cast<float *>(g_max_ring_ptr[dev]) + 2 * (g_max_ring_next.fetch_add(1) % kMaxRing);
+    *out = static_cast<float *>(q) + 2 * (g_max_ring_next.fetch_add(1) % kMaxRing);
     return DLRM_OK;
 }
 
@@ -1116,7 +1112,7 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
                                 l->act == DLRM_ACT_RELU, l->d_y_absmax, as_stream(stream));
     if (l->N == 1 && gemv_ok(l->d_x, l->x_ld, l->d_w, l->K))
         return gemv_forward(l->d_x, l->x_ld, l->d_w, l->d_bias, l->d_y, l->y_ld, (int)l->M, l->K, l->act == DLRM_ACT_RELU,
-                            as_stream(stream));
+                            l->d_y_absmax, as_stream(stream));
     GemmParams p{};
     p.A = l->d_x; p.lda = l->x_ld; p.B = l->d_w; p.ldb = l->w_ld; p.C = l->d_y; p.ldc = l->y_ld;
     p.M = (int)l->M; p.N = l->N; p.K = l->K; p.bias = l->d_bias; p.relu = l->act == DLRM_ACT_RELU;
@@ -1233,19 +1229,19 @@ extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_wor
 static __device__ __align__(256) unsigned char scratch[DLRM_STATIC_SCRATCH_BYTES];
 
 constexpr int kMaxDevices = 64;
-static void *g_scratch_ptr[kMaxDevices];   // [device] address of that device's copy of `scratch`, NULL = not asked yet
+static std::atomic<void *> g_scratch_ptr[kMaxDevices];   // [device] address of that device's copy of `scratch`, NULL = not asked yet
 
 static int static_scratch(void **out) {
     int dev = -1;
     DLRM_HIP(hipGetDevice(&dev));
     DLRM_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
-    if (g_scratch_ptr[dev] == nullptr) {
-        void *p = nullptr;
+    void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
         DLRM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         DLRM_REQUIRE(p != nullptr, "hipGetSymbolAddress returned NULL for the static scratch array");
-        g_scratch_ptr[dev] = p;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
     }
-    *out = g_scratch_ptr[dev];
+    *out = p;
     return DLRM_OK;
 }
 

@@ -17,10 +17,10 @@ int skinny_k_forward(const float *x, int64_t x_ld, const float *w, int64_t w_ld,
 int skinny_k_backward_weight(const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, float *slabs, float *db_slabs,
                              int M, int N, int K, int max_chunks, int *chunks, hipStream_t s);
 
-// N == 1: y[m] = act(x[m,:] . w + b)
+// N == 1: y[m] = act(x[m,:] . w + b); y_max (or NULL): max |y| is folded into it
 bool gemv_ok(const void *x, int64_t x_ld, const void *w, int K);
 int gemv_forward(const float *x, int64_t x_ld, const float *w, const float *bias, float *y, int64_t y_ld, int M, int K, int relu,
-                 hipStream_t s);
+                 float *y_max, hipStream_t s);
 // dx[m,k] = dz[m] w[k], zero where mask[m,k] <= 0; dx_max (or NULL): max |dx| is folded into it
 int gemv_backward_data(const float *dz, int64_t dz_ld, const float *w, float *dx, int64_t dx_ld, const float *mask,
                        int64_t mask_ld, int M, int K, float *dx_max, hipStream_t s);

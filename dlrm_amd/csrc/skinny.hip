@@ -111,9 +111,11 @@ __global__ __launch_bounds__(kSkThreads) void skinny_k_bwd_weight_kernel(const f
 // 16 lanes per row, 16 bytes each per trip
 __global__ __launch_bounds__(kSkThreads) void gemv_fwd_kernel(const float *__restrict__ x, int64_t x_ld,
                                                                const float *__restrict__ w, const float *__restrict__ bias,
-                                                               float *__restrict__ y, int64_t y_ld, int M, int K, int relu) {
+                                                               float *__restrict__ y, int64_t y_ld, int M, int K, int relu,
+                                                               float *__restrict__ y_max) {
     const int lig = threadIdx.x & 15;
     const float b = bias ? bias[0] : 0.f;
+    float vmax = 0.f;
     for (int m = blockIdx.x * (kSkThreads / 16) + (threadIdx.x >> 4); m < M; m += gridDim.x * (kSkThreads / 16)) {
         const float *xr = x + (int64_t)m * x_ld;
         float a = 0.f;
@@ -126,9 +128,12 @@ __global__ __launch_bounds__(kSkThreads) void gemv_fwd_kernel(const float *__res
         for (int s = 8; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
         if (lig == 0) {
             a += b;
-            y[(int64_t)m * y_ld] = relu ? fmaxf(a, 0.f) : a;
+            a = relu ? fmaxf(a, 0.f) : a;
+            y[(int64_t)m * y_ld] = a;
+            vmax = fmaxf(vmax, fabsf(a));
         }
     }
+    if (y_max != nullptr) fold_absmax_block(vmax, y_max);
 }
 
 __global__ __launch_bounds__(kSkThreads) void gemv_bwd_data_kernel(const float *__restrict__ dz, int64_t dz_ld,
@@ -252,10 +257,10 @@ bool gemv_ok(const void *x, int64_t x_ld, const void *w, int K) {
 }
 
 int gemv_forward(const float *x, int64_t x_ld, const float *w, const float *bias, float *y, int64_t y_ld, int M, int K, int relu,
-                 hipStream_t s) {
+                 float *y_max, hipStream_t s) {
     const int64_t blocks = ceil_div(M, kSkThreads / 16);
     hipLaunchKernelGGL(gemv_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kSkThreads), 0, s, x, x_ld, w, bias,
-                       y, y_ld, M, K, relu);
+                       y, y_ld, M, K, relu, y_max);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }
