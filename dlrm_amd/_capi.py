@@ -22,7 +22,7 @@ class DlrmError(RuntimeError):
     pass
 
 
-ABI_VERSION = 1013   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
+ABI_VERSION = 1014   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
 
 
 class EmbBagDesc(C.Structure):
@@ -65,6 +65,7 @@ class LinearDesc(C.Structure):
         ("act", C.c_int32),
         ("gemm_mode", C.c_int32),
         ("d_x_absmax", C.c_void_p), ("d_w_absmax", C.c_void_p), ("d_y_absmax", C.c_void_p),
+        ("w_planes", C.c_void_p),
     ]
 
 
@@ -80,6 +81,14 @@ class LinearBwdDesc(C.Structure):
         ("d_db", C.c_void_p),
         ("gemm_mode", C.c_int32),
         ("d_dz_absmax", C.c_void_p), ("d_w_absmax", C.c_void_p), ("d_x_absmax", C.c_void_p), ("d_dx_absmax", C.c_void_p),
+        ("w_planes", C.c_void_p),
+    ]
+
+
+class WeightPlanes(C.Structure):
+    _fields_ = [
+        ("d_w", C.c_void_p), ("w_ld", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+        ("d_w_absmax", C.c_void_p), ("d_planes", C.c_void_p),
     ]
 
 

@@ -72,6 +72,8 @@ struct GemmParams {
                           // (the bias gradient of the weight-gradient product), or NULL
     const float *a_max, *b_max;   // f16x2 evaluation: device scalars holding max |A|, max |B| (float32 bit patterns)
     float *c_max;         // or NULL: max |C| over everything this launch stores is folded in with atomicMax
+    const unsigned char *bp_h, *bp_l;   // gemm_f16p_kernel: the f16 planes of B [N rounded up to 128][bp_ld bytes], zero padded
+    int64_t bp_ld;
 };
 
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
@@ -158,11 +160,11 @@ __device__ inline void load_frag(const float *__restrict__ s, int o_base, int q,
 // (32 MI) x (32 NI) block at a time in LDS (`ct`: 4 waves x 32 x (32 NI + 4) floats, the staging buffers are
 // free by now) and streams them out as 16-byte row segments -- 8 NI lanes per row piece -- with
 // bias / ReLU / mask fused.
-template <int MI, int NI>
+template <int MI, int NI, int WC = 2>     // (WC: waves side by side along the columns of the workgroup's tile)
 __device__ inline void store_output(const GemmParams &p, const f32x16 (&acc)[MI][NI], float *ct_all, int m0, int n0,
                                     int bz) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave % WC;
     float *C = p.C + (int64_t)bz * p.slab_stride;
     constexpr int CT_LD = 32 * NI + 4;
     constexpr int LPR = 8 * NI;           // lanes per row piece
@@ -824,6 +826,245 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams 
     store_output<MI, NI>(p, acc, fsm, m0, n0, bz);
 }
 
+// ---------------------------------------------------------------------------------------------
+// f16x2 evaluation of C = A B^T with B cut into its two f16 planes BEFOREHAND (dlrm_split_weights: B is a weight
+// matrix, a few MB that every one of the hundreds of row tiles would otherwise split again), for the forward
+// (A = x, B = W) and backward-data (A = dz, B = W^T, planes of the transposed matrix) products of the big layers.
+//
+// 128 x 128 outputs per 256-thread workgroup, 32-deep reduction steps.  Wave w owns rows 32w .. 32w+31 and all 128
+// columns (4 MFMA tiles of 32 x 32, two accumulators each: see split2_pair).  The A operand never touches LDS:
+// lane (row r, half h) of a wave reads ITS 16 reduction elements of the step -- 64 contiguous bytes of row r -- from
+// global memory, splits them in registers and uses the pieces as its MFMA A fragments (first 8 elements in the first
+// of the step's two 16-deep MFMA slices, the other 8 in the second: the reduction index of MFMA position (h, j) of
+// slice s is 16 h + 8 s + j, and the B planes are read from LDS in the same order).  So A costs no LDS write, no
+// fragment read and waits for no barrier; only the B planes (16 KB per step: 128 x 32 f16, two planes) go through a
+// two-stage LDS ring, one barrier per step.  Against gemm_split_kernel<.., 2>: half the split arithmetic (A only, and
+// every A element is split by exactly one lane), a quarter of the LDS write instructions, half the barriers.
+//   LDS image of a plane: [128][32] f16, 64-byte rows whose 16-byte chunks are XOR-swizzled with bits 2..3 of the row
+//   (conflict-free ds_write_b128 of the incoming pieces and ds_read_b128 of the fragments)
+constexpr int kPStage = 2 * 128 * 64;       // bytes per stage: h plane, l plane
+
+__device__ inline int bp_lds_off(int n, int c) { return n * 64 + 16 * (c ^ ((n >> 2) & 3)); }
+
+// TAIL (K is no multiple of 32): elements at or beyond k_left are zeroed (every step of such a launch pays the
+// selects: the choice is per kernel, not per step, so that a step's body stays one straight-line region)
+template <bool TAIL>
+__device__ inline void f16p_split(const f32x4 (&r)[4], float scale, int k_left, bf16x8 (&f)[2][2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            f32x4 x = r[2 * s + q];
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] = (8 * s + 4 * q + e) < k_left ? x[e] : 0.f;
+            }
+            split2_pair(f32x2{x[0], x[1]}, scale, h[2 * q], l[2 * q]);
+            split2_pair(f32x2{x[2], x[3]}, scale, h[2 * q + 1], l[2 * q + 1]);
+        }
+        f[s][0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+        f[s][1] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    }
+}
+
+// scheduling recipe of a step: the 16 fragment reads early (8 up front, the rest behind the first MFMAs), the next
+// step's split (about 80 vector operations) spread behind the MFMAs
+template <int I>
+__device__ inline void f16p_interleave() {
+    if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if constexpr (I < 24) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        // the second slice's fragments of column tile k once the first slice's MFMAs on that tile have issued
+        if constexpr (I < 12 && I % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, I < 8 ? 3 : 4, 0);
+        f16p_interleave<I + 1>();
+    }
+}
+
+template <bool TAIL>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p) {
+    constexpr int kOutStaging = 4 * 32 * (64 + 4) * 4;    // the epilogue parks 32 x 64 per wave at a time
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage > kOutStaging ? 2 * kPStage : kOutStaging];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const float scale_a = split2_scale(__float_as_uint(*p.a_max));
+    const float scale_b = split2_scale(__float_as_uint(*p.b_max));
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int nwg = p.gx * p.gy;
+    const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int bx = tile % p.gx, by = tile / p.gx;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int steps = (p.K + 31) / 32;
+
+    // A: this lane's row (clamped: surplus rows only feed outputs that are never stored) and its 64 bytes of a step
+    const int row = m0 + 32 * wave + l31;
+    const int rowc = row < p.M ? row : p.M - 1;
+    const float *a_origin = p.A + (int64_t)m0 * p.lda;
+    const unsigned a_off = (unsigned)((rowc - m0) * (int)p.lda + 16 * half) * 4u;
+    // B planes go global -> LDS directly (buffer_load ... lds: 64 lanes x 16 bytes land side by side, 16 rows of the
+    // image per instruction).  Waves 0, 1 bring the h plane's rows 0..63 / 64..127, waves 2, 3 the l plane's, four
+    // instructions each; the swizzle is applied on the global side: the lane that fills position pp of row n fetches
+    // the row's chunk pp ^ ((n >> 2) & 3).
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 64 * (uwave & 1)) * p.bp_ld;
+    const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * ((lane & 3) ^ ((lane >> 4) & 3)));
+    const unsigned b_off16 = (unsigned)(16 * (int)p.bp_ld);
+    const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;       // this wave's 4 KB of a stage
+    (void)tid;
+    const int rd0 = bp_lds_off(l31, 2 * half), rd1 = bp_lds_off(l31, 2 * half + 1);   // slice 0 / 1, + 2048 per column tile
+
+    f32x16 hi[4], lo[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { hi[ni][r] = 0.f; lo[ni][r] = 0.f; }
+
+    auto load_a = [&](int t, f32x4 (&r)[4]) {
+        const int tc = t < steps ? t : steps - 1;     // (surplus requests re-read the last step)
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_origin + 32 * tc), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            r[q] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a_off + 16 * q), 0, 0));
+    };
+    auto load_b = [&](int t, unsigned char *stage) {
+        const int tc = t < steps ? t : steps - 1;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
+        typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(stage + b_lds + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
+    };
+    // the 24 MFMAs of one step: slice s pairs A pieces af[s] with the B fragments at chunk (2 half + s)
+    auto mfma_step = [&](const unsigned char *stage, const bf16x8 (&af)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, af[s][0]), al = __builtin_bit_cast(f16x8, af[s][1]);
+            const int rd = s ? rd1 : rd0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const f16x8 bh = *reinterpret_cast<const f16x8 *>(stage + rd + ni * 2048);
+                const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 8192 + rd + ni * 2048);
+                f32x16 c = lo[ni];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+                lo[ni] = c;
+                hi[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, hi[ni], 0, 0, 0);
+            }
+        }
+    };
+    unsigned char *const s0 = smem, *const s1 = smem + kPStage;
+    f32x4 ra[4], rb[4];           // raw A of two steps in turn
+    bf16x8 fa[2][2], fb[2][2];    // A pieces of two steps in turn
+    // step t: MFMAs on (stage_c, f_c); meanwhile raw_n (step t+1, requested one step ago) is split into f_n, the B
+    // pieces of step t+1 go to stage_n, and step t+2's A is requested into raw_c (whose step has been split already)
+    auto step = [&](int t, unsigned char *stage_c, unsigned char *stage_n, f32x4 (&raw_c)[4], f32x4 (&raw_n)[4],
+                    bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
+        load_b(t + 1, stage_n);        // (every wave has passed the barrier behind its last read of stage_n)
+        load_a(t + 2, raw_c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pin_here(raw_n[q]);
+        f16p_split<TAIL>(raw_n, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
+        mfma_step(stage_c, f_c);
+        f16p_interleave<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of stage_n have landed (the four A requests issued behind them may stay in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F74);
+        __syncthreads();
+    };
+    load_a(0, ra);
+    load_b(0, s0);
+    load_a(1, rb);
+    f16p_split<TAIL>(ra, scale_a, p.K - 16 * half, fa);
+    __builtin_amdgcn_s_waitcnt(0x0F74);
+    __syncthreads();
+    // pairs of steps, no branch inside the loop (control flow that merges the 128 accumulator registers of several
+    // step bodies costs copies and spills); an odd last step follows it
+    int t = 0;
+    for (; t + 1 < steps; t += 2) {
+        step(t, s0, s1, ra, rb, fa, fb);
+        step(t + 1, s1, s0, rb, ra, fb, fa);
+    }
+    if (t < steps) step(t, s0, s1, ra, rb, fa, fb);
+
+    const float inv_a = 1.0f / scale_a, inv_b = 1.0f / scale_b;
+    float *fsm = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int hn = 0; hn < 2; hn++) {      // two column halves of 64: mixed terms in, operand scales out, then the usual epilogue
+        f32x16 o[1][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                o[0][ni][r] = (__builtin_fmaf(lo[2 * hn + ni][r], kSplit2LowInv, hi[2 * hn + ni][r]) * inv_a) * inv_b;
+        store_output<1, 2, 1>(p, o, fsm, m0, n0 + 64 * hn, 0);
+    }
+}
+
+// ---- the planes gemm_f16p_kernel reads: for a weight matrix W [N,K], its f16 pieces (times the scale of max |W|) as
+// [N rounded up to 128][K rounded up to 32] (forward: reduction over K) and, transposed, [K rounded up to 128][N
+// rounded up to 32] (backward-data: reduction over N), zero in the padding.  Layout of the buffer: forward h, forward
+// l, transposed h, transposed l.
+struct PlaneDims { int64_t f_rows, f_ld, t_rows, t_ld; };     // rows and leading dimension (f16 elements) of the two images
+static PlaneDims plane_dims(int N, int K) {
+    return PlaneDims{ceil_div(N, 128) * 128, ceil_div(K, 32) * 32, ceil_div(K, 128) * 128, ceil_div(N, 32) * 32};
+}
+static size_t plane_bytes_total(int N, int K) {
+    const PlaneDims d = plane_dims(N, K);
+    return (size_t)2 * 2 * (d.f_rows * d.f_ld + d.t_rows * d.t_ld);
+}
+
+struct SplitJob {
+    const float *w;
+    int64_t ld;
+    int N, K;
+    const unsigned *amax;
+    _Float16 *fh, *fl, *th, *tl;
+    PlaneDims d;
+};
+struct SplitJobs { SplitJob j[kAbsmaxMany]; };
+
+__device__ inline void split2_one(float x, float scale, _Float16 &h, _Float16 &l) {
+    const float xs = x * scale;
+    h = (_Float16)xs;
+    l = (_Float16)((xs - (float)h) * kSplit2LowScale);
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(SplitJobs jobs) {
+    const SplitJob j = jobs.j[blockIdx.y];
+    const float scale = split2_scale(*j.amax);
+    // forward image: consecutive threads along k (coalesced reads and writes)
+    const int64_t nf = j.d.f_rows * j.d.f_ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / j.d.f_ld, k = i - n * j.d.f_ld;
+        const float x = (n < j.N && k < j.K) ? j.w[n * j.ld + k] : 0.f;
+        _Float16 h, l;
+        split2_one(x, scale, h, l);
+        j.fh[i] = h; j.fl[i] = l;
+    }
+    // transposed image: consecutive threads along n (coalesced writes; the strided reads of a wave stay within the
+    // 64 lines it walks along k)
+    const int64_t n_blocks = j.d.t_ld / 32, k_blocks = j.d.t_rows / 32;     // 32 x 32 blocks, one per wave trip
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < n_blocks * k_blocks; b += (int64_t)gridDim.x * 4) {
+        const int64_t nb = b % n_blocks, kb = b / n_blocks;
+        const int64_t n = nb * 32 + (lane & 31);
+#pragma unroll 4
+        for (int kk = (lane >> 5); kk < 32; kk += 2) {
+            const int64_t k = kb * 32 + kk;
+            const float x = (n < j.N && k < j.K) ? j.w[n * j.ld + k] : 0.f;
+            _Float16 h, l;
+            split2_one(x, scale, h, l);
+            j.th[k * j.d.t_ld + n] = h; j.tl[k * j.d.t_ld + n] = l;
+        }
+    }
+}
+
 // out[i] = sum_s slabs[s*stride + i] for an [rows, cols] matrix (ld_out).  A 256-thread workgroup owns
 // 64 consecutive outputs; thread (q, e) adds the slabs s = q, q+4, ... of output e with eight loads in
 // flight, and the four partial sums meet in LDS in a fixed order (deterministic).  One launch serves two
@@ -1076,6 +1317,40 @@ static int launch_gemm(GemmParams p, int splits, TileShape ts, int mode, hipStre
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+// DLRM_F16P=0 keeps the pre-split planes unused (A/B timing)
+static bool f16p_enabled() {
+    static const bool on = [] { const char *e = getenv("DLRM_F16P"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// C [M,N] = A [M,K] times the planes of a weight matrix (`transposed`: of its transpose), through gemm_f16p_kernel when
+// the shape suits it: p carries A, C, the epilogue fields and both maxima.  *done = false: the caller takes its
+// general path (small grids keep the smaller tiles of gemm_split_kernel).
+static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transposed, const float *w, int64_t w_ld, bool *done,
+                       hipStream_t s) {
+    *done = false;
+    if (wp == nullptr || !f16p_enabled()) return DLRM_OK;
+    DLRM_REQUIRE(wp->d_planes != nullptr && wp->d_w == w && wp->w_ld == w_ld &&
+                     (transposed ? (wp->N == p.K && wp->K == p.N) : (wp->N == p.N && wp->K == p.K)),
+                 "w_planes do not belong to this layer's weight matrix");
+    const int64_t k32 = ceil_div(p.K, 32) * 32;
+    if (!p.a_vec || (p.K % 32 != 0 && p.lda < k32)) return DLRM_OK;
+    p.gx = (int)ceil_div(p.N, 128); p.gy = (int)ceil_div(p.M, 128); p.gz = 1;
+    if ((int64_t)p.gx * p.gy < kTileWgs) return DLRM_OK;
+    const PlaneDims d = plane_dims(wp->N, wp->K);
+    const unsigned char *base = static_cast<const unsigned char *>(wp->d_planes);
+    if (!transposed) { p.bp_h = base; p.bp_l = base + 2 * d.f_rows * d.f_ld; p.bp_ld = 2 * d.f_ld; }
+    else {
+        base += 4 * d.f_rows * d.f_ld;
+        p.bp_h = base; p.bp_l = base + 2 * d.t_rows * d.t_ld; p.bp_ld = 2 * d.t_ld;
+    }
+    if (p.K % 32 != 0) hipLaunchKernelGGL(gemm_f16p_kernel<true>, dim3((unsigned)(p.gx * p.gy)), dim3(kGemmThreads), 0, s, p);
+    else hipLaunchKernelGGL(gemm_f16p_kernel<false>, dim3((unsigned)(p.gx * p.gy)), dim3(kGemmThreads), 0, s, p);
+    DLRM_LAUNCH_CHECK();
+    *done = true;
+    return DLRM_OK;
+}
 // rows of an operand start on 16-byte boundaries (otherwise the kernel falls back to 4-byte loads)
 static int vec_ok(const void *p, int64_t ld) { return aligned16(p) && ld % 4 == 0; }
 
@@ -1099,6 +1374,37 @@ extern "C" int dlrm_absmax(const float *d_x, int64_t rows, int32_t cols, int64_t
     return launch_absmax(d_x, rows, cols, ld, d_slot, as_stream(stream));
 }
 
+extern "C" int dlrm_weight_planes_bytes(int32_t N, int32_t K, size_t *bytes) {
+    DLRM_REQUIRE(bytes != nullptr && N >= 1 && K >= 1, "bad arguments");
+    *bytes = plane_bytes_total(N, K);
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_split_weights(const dlrm_weight_planes *items, int32_t n, dlrm_stream_t stream) {
+    DLRM_REQUIRE(n >= 0 && (n == 0 || items != nullptr), "bad arguments");
+    for (int i0 = 0; i0 < n; i0 += kAbsmaxMany) {
+        SplitJobs jobs{};
+        const int cnt = n - i0 < kAbsmaxMany ? n - i0 : kAbsmaxMany;
+        int64_t most = 1;
+        for (int i = 0; i < cnt; i++) {
+            const dlrm_weight_planes &w = items[i0 + i];
+            DLRM_REQUIRE(w.d_w && w.d_w_absmax && w.d_planes && w.N >= 1 && w.K >= 1 && w.w_ld >= w.K, "bad weight_planes item %d", i0 + i);
+            DLRM_REQUIRE(aligned16(w.d_planes), "planes must be 16-byte aligned");
+            SplitJob &j = jobs.j[i];
+            j.w = w.d_w; j.ld = w.w_ld; j.N = w.N; j.K = w.K; j.amax = reinterpret_cast<const unsigned *>(w.d_w_absmax);
+            j.d = plane_dims(w.N, w.K);
+            j.fh = static_cast<_Float16 *>(w.d_planes); j.fl = j.fh + j.d.f_rows * j.d.f_ld;
+            j.th = j.fl + j.d.f_rows * j.d.f_ld; j.tl = j.th + j.d.t_rows * j.d.t_ld;
+            const int64_t b = ceil_div(j.d.f_rows * j.d.f_ld, 256 * 8);
+            most = b > most ? b : most;
+        }
+        most = most > 256 ? 256 : most;
+        hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)most, (unsigned)cnt), dim3(256), 0, as_stream(stream), jobs);
+        DLRM_LAUNCH_CHECK();
+    }
+    return DLRM_OK;
+}
+
 extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     DLRM_REQUIRE(l != nullptr, "linear descriptor is NULL");
     DLRM_REQUIRE(l->M >= 0 && l->N >= 1 && l->K >= 1, "bad shape M=%lld N=%d K=%d", (long long)l->M, l->N, l->K);
@@ -1119,8 +1425,12 @@ extern "C" int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream) {
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->K, BK) * BK;
     p.c_max = l->d_y_absmax;
-    if (l->gemm_mode == DLRM_GEMM_F16X2)
+    if (l->gemm_mode == DLRM_GEMM_F16X2) {
         if (int rc = operand_maxima(p, l->d_x_absmax, l->M, l->K, l->d_w_absmax, l->N, l->K, as_stream(stream))) return rc;
+        bool done = false;
+        if (int rc = launch_f16p(p, l->w_planes, false, l->d_w, l->w_ld, &done, as_stream(stream))) return rc;
+        if (done) return DLRM_OK;
+    }
     return launch_gemm<true, true>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 
@@ -1142,8 +1452,12 @@ extern "C" int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t
     p.a_vec = vec_ok(p.A, p.lda); p.b_vec = vec_ok(p.B, p.ldb);
     p.k_per_split = (int)ceil_div(l->N, BK) * BK;
     p.c_max = l->d_dx_absmax;
-    if (l->gemm_mode == DLRM_GEMM_F16X2)    // (B = W [N,K]: rows are reduction indices)
+    if (l->gemm_mode == DLRM_GEMM_F16X2) {    // (B = W [N,K]: rows are reduction indices)
         if (int rc = operand_maxima(p, l->d_dz_absmax, l->M, l->N, l->d_w_absmax, l->N, l->K, as_stream(stream))) return rc;
+        bool done = false;
+        if (int rc = launch_f16p(p, l->w_planes, true, l->d_w, l->w_ld, &done, as_stream(stream))) return rc;
+        if (done) return DLRM_OK;
+    }
     return launch_gemm<true, false>(p, 1, pick_tile(p.M, p.N, 0, nullptr), l->gemm_mode, as_stream(stream));
 }
 

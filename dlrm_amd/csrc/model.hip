@@ -34,6 +34,7 @@ struct Layer {
     int N, K;
     int64_t w_off, w_ld, b_off;   // offsets into the flat parameter / gradient buffers
     int s_x = -1, s_w = -1, s_dz = -1;   // f16x2 evaluation: slots of max |input|, max |W|, max |dz| in dlrm_model::amax
+    dlrm_weight_planes planes{};         // f16x2 evaluation: the matrix cut into its f16 pieces once per pass (d_planes NULL: not kept)
 };
 
 struct Act {   // a [B, n] activation: pointer + leading dimension
@@ -180,7 +181,15 @@ static int begin_pass_maxima(dlrm_model *m, hipStream_t s) {
                 items.push_back(AbsmaxItem{m->params + l.w_off, l.N, l.K, l.w_ld, m->amax + l.s_w});
                 m->amax_valid[l.s_w] = 1;
             }
-    return items.empty() ? DLRM_OK : absmax_many(items.data(), (int)items.size(), s);
+    if (items.empty()) return DLRM_OK;
+    if (int rc = absmax_many(items.data(), (int)items.size(), s)) return rc;
+    // ... and their f16 pieces, one launch: the forward and backward-data products of this pass read them instead of
+    // splitting the matrix again in every one of their row tiles
+    std::vector<dlrm_weight_planes> planes;
+    for (auto *st : {&m->bot, &m->topl})
+        for (const Layer &l : *st)
+            if (l.planes.d_planes) planes.push_back(l.planes);
+    return planes.empty() ? DLRM_OK : dlrm_split_weights(planes.data(), (int32_t)planes.size(), s);
 }
 
 static int need_max(dlrm_model *m, int slot, const float *x, int cols, int64_t ld, int64_t rows, hipStream_t s) {
@@ -207,6 +216,7 @@ static int linear_fwd(dlrm_model *m, const Layer &l, const float *x, int64_t x_l
         if (int rc = need_max(m, l.s_w, d.d_w, l.K, l.w_ld, l.N, s)) return rc;
         d.gemm_mode = DLRM_GEMM_F16X2;
         d.d_x_absmax = m->amax + l.s_x; d.d_w_absmax = m->amax + l.s_w;
+        if (l.planes.d_planes) d.w_planes = &l.planes;
     }
     if (m->f16x2) d.d_y_absmax = out_slot(m, y_slot);    // (the narrow layers' kernels leave their maximum behind too)
     return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_FORWARD_SKINNY : DLRM_TIME_LINEAR_FORWARD, s,
@@ -223,6 +233,7 @@ static int linear_dgrad(dlrm_model *m, const Layer &l, int64_t col0, int K, cons
         if (int rc = need_max(m, l.s_w, m->params + l.w_off, l.K, l.w_ld, l.N, s)) return rc;   // (of the whole matrix)
         d.gemm_mode = DLRM_GEMM_F16X2;
         d.d_dz_absmax = m->amax + l.s_dz; d.d_w_absmax = m->amax + l.s_w;
+        if (l.planes.d_planes && col0 == 0 && K == l.K) d.w_planes = &l.planes;    // (a column slice of W splits in the kernel)
     }
     if (m->f16x2) d.d_dx_absmax = out_slot(m, dx_slot);
     return timed(m, l.N == 1 ? DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY : DLRM_TIME_LINEAR_BACKWARD_DATA, s,
@@ -592,6 +603,16 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     }
     if ((rc = dalloc(m, &m->params, (size_t)off))) return fail(rc);
     if ((rc = dalloc(m, &m->grads, (size_t)off))) return fail(rc);
+    if (m->f16x2)
+        for (auto *st : {&m->bot, &m->topl})
+            for (Layer &l : *st)
+                if (big_layer(m, l)) {
+                    size_t bytes = 0;
+                    if ((rc = dlrm_weight_planes_bytes(l.N, l.K, &bytes))) return fail(rc);
+                    unsigned char *pl = nullptr;
+                    if ((rc = dalloc(m, &pl, bytes))) return fail(rc);
+                    l.planes = dlrm_weight_planes{m->params + l.w_off, l.w_ld, l.N, l.K, m->amax + l.s_w, pl};
+                }
 
     // ---- activations
     const size_t B = (size_t)m->B;

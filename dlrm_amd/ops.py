@@ -206,12 +206,38 @@ def _ld(t):
     return t.stride(0)
 
 
+class SplitWeights:
+    """The f16 planes of a weight matrix as dlrm_split_weights leaves them (f16x2 evaluation): keeps the device
+    buffers and the host descriptor alive; pass it as w_planes= to linear_forward / linear_backward_data together with
+    w_absmax=self.absmax.  Split again after the matrix changes."""
+
+    def __init__(self, w):
+        _require_cuda(w)
+        N, K = w.shape
+        nbytes = C.c_size_t()
+        check(_capi.lib().dlrm_weight_planes_bytes(N, K, C.byref(nbytes)))
+        self.w = w
+        self.absmax = torch.zeros(1, dtype=torch.float32, device=w.device)
+        self.planes = torch.empty(nbytes.value, dtype=torch.uint8, device=w.device)
+        self.item = _capi.WeightPlanes(w.data_ptr(), _ld(w), N, K, self.absmax.data_ptr(), self.planes.data_ptr())
+        self.split()
+
+    def split(self):
+        self.absmax.zero_()
+        check(_capi.lib().dlrm_absmax(C.c_void_p(self.w.data_ptr()), C.c_int64(self.w.shape[0]), C.c_int32(self.w.shape[1]),
+                                      C.c_int64(_ld(self.w)), C.c_void_p(self.absmax.data_ptr()), _stream()))
+        check(_capi.lib().dlrm_split_weights(C.byref(self.item), 1, _stream()))
+
+    def ptr(self):
+        return C.addressof(self.item)
+
+
 @_op
-def linear_forward(x, w, bias, relu, out=None, x_absmax=None, w_absmax=None, y_absmax=None):
+def linear_forward(x, w, bias, relu, out=None, x_absmax=None, w_absmax=None, y_absmax=None, w_planes=None):
     """y = act(x W^T + b).  x [M,K] and w [N,K] may be column slices of wider
     (padded) buffers: the row stride is passed as the leading dimension.
     *_absmax (f16x2 mode): one-element float32 tensors holding max |x|, max |W| (None: measured by the call) and
-    receiving max |y| (atomicMax: zero it first)."""
+    receiving max |y| (atomicMax: zero it first).  w_planes (f16x2 mode): a SplitWeights of w."""
     _require_cuda(x, w, bias, out)
     M, K = x.shape
     N = w.shape[0]
@@ -227,13 +253,15 @@ def linear_forward(x, w, bias, relu, out=None, x_absmax=None, w_absmax=None, y_a
     d.act = _capi.ACT_RELU if relu else _capi.ACT_NONE
     d.gemm_mode = _gemm_field()
     d.d_x_absmax, d.d_w_absmax, d.d_y_absmax = _ptr0(x_absmax), _ptr0(w_absmax), _ptr0(y_absmax)
+    if w_planes is not None:
+        d.w_planes, d.d_w_absmax = w_planes.ptr(), w_planes.absmax.data_ptr()
     _emit("linear_forward", d)
     return out
 
 
 @_op
-def linear_backward_data(dz, w, relu_mask=None, out=None, dz_absmax=None, w_absmax=None, dx_absmax=None):
-    """dx = dz W, optionally masked with (relu_mask > 0).  *_absmax: see linear_forward."""
+def linear_backward_data(dz, w, relu_mask=None, out=None, dz_absmax=None, w_absmax=None, dx_absmax=None, w_planes=None):
+    """dx = dz W, optionally masked with (relu_mask > 0).  *_absmax, w_planes: see linear_forward."""
     _require_cuda(dz, w, relu_mask, out)
     M, N = dz.shape
     K = w.shape[1]
@@ -248,6 +276,8 @@ def linear_backward_data(dz, w, relu_mask=None, out=None, dz_absmax=None, w_absm
         d.d_relu_mask, d.relu_mask_ld = relu_mask.data_ptr(), _ld(relu_mask)
     d.gemm_mode = _gemm_field()
     d.d_dz_absmax, d.d_w_absmax, d.d_dx_absmax = _ptr0(dz_absmax), _ptr0(w_absmax), _ptr0(dx_absmax)
+    if w_planes is not None:
+        d.w_planes, d.d_w_absmax = w_planes.ptr(), w_planes.absmax.data_ptr()
     _emit("linear_backward_data", d)
     return out
 

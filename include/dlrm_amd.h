@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1013
+#define DLRM_ABI_VERSION 1014
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -203,6 +203,27 @@ int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_
 enum { DLRM_GEMM_DEFAULT = 0, DLRM_GEMM_F32_MFMA = 1, DLRM_GEMM_BF16X3 = 2, DLRM_GEMM_F16X2 = 3 };
 
 /*
+ * DLRM_GEMM_F16X2 with a layer's weights cut into their f16 pieces ONCE per step instead of by every workgroup of
+ * every product that reads them (no counterpart in the reference).  dlrm_split_weights writes, for each item, the
+ * two f16 planes of W and of W^T (scaled by the power of two that *d_w_absmax implies, zero padded to whole tiles)
+ * into d_planes; a dlrm_linear / dlrm_linear_bwd whose w_planes points at the item then runs its forward /
+ * backward-data product through a kernel that reads those planes (same arithmetic, same results as the in-kernel
+ * split up to the order of the float32 accumulation).  The planes describe W as it was when dlrm_split_weights
+ * ran: split again after every optimizer step.  The item is host memory that must stay valid while descriptors
+ * (or a recorded dlrm_plan) refer to it.
+ */
+typedef struct dlrm_weight_planes {
+    const float *d_w;          /* [N,K] */
+    int64_t w_ld;
+    int32_t N, K;
+    const float *d_w_absmax;   /* device scalar: max |W| (dlrm_absmax), complete on the stream before dlrm_split_weights runs */
+    void *d_planes;            /* dlrm_weight_planes_bytes(N, K) bytes of device memory, 16-byte aligned */
+} dlrm_weight_planes;
+
+int dlrm_weight_planes_bytes(int32_t N, int32_t K, size_t *bytes);
+int dlrm_split_weights(const dlrm_weight_planes *items, int32_t n, dlrm_stream_t stream);
+
+/*
  * y = act(x W^T + bias): one torch::nn::Linear + torch::relu of Net2::forward
  * (src/dlrmtest.cpp:254-272; layers made by create_fc, :119-140).  W is [N,K]
  * row-major (torch layout).  Any shape and leading dimension is accepted (K = 13, 479, ...);
@@ -228,6 +249,8 @@ typedef struct dlrm_linear {
      * the operand in a pass of its own), and a scalar into which max |y| is folded with atomicMax (start it at 0) */
     const float *d_x_absmax, *d_w_absmax;
     float *d_y_absmax;
+    /* DLRM_GEMM_F16X2 only, may be NULL: the pre-split planes of d_w (dlrm_split_weights); needs d_w_absmax = the item's */
+    const dlrm_weight_planes *w_planes;
 } dlrm_linear;
 
 int dlrm_linear_forward(const dlrm_linear *l, dlrm_stream_t stream);
@@ -274,6 +297,8 @@ typedef struct dlrm_linear_bwd {
      * (backward_weight); max |dx| is folded into *d_dx_absmax (backward_data) */
     const float *d_dz_absmax, *d_w_absmax, *d_x_absmax;
     float *d_dx_absmax;
+    /* DLRM_GEMM_F16X2 only, may be NULL: the pre-split planes of d_w (backward_data; see dlrm_linear) */
+    const dlrm_weight_planes *w_planes;
 } dlrm_linear_bwd;
 
 int dlrm_linear_backward_data(const dlrm_linear_bwd *l, dlrm_stream_t stream);

@@ -1,10 +1,12 @@
-"""MLP GEMMs (fp32 MFMA), dot interaction and losses: HIP kernels vs the CPU
-oracle (double accumulation).
+"""MLP GEMMs, dot interaction and losses: HIP kernels vs the CPU oracle (double accumulation).
 
-Tolerance: 1e-5 relative to the largest |reference| value of each tensor.  The
-MFMA path is a k-ordered fp32 fma chain; for the deepest reductions used here
-(K = 1024 forward, batch = 2048 in the weight gradient) its rounding error
-relative to the tensor scale stays below that bound on N(0,1) data."""
+Every test of the layer products runs in the three evaluations of the float32 products (float32 MFMA chain; three
+bf16 pieces, six cross terms; two f16 pieces, three cross terms), see the gemm_mode fixture.
+
+Tolerance: 1e-5 relative to the largest |reference| value of each tensor, and element by element
+|err| <= 1e-5 |ref| + 8 * 2^-24 * sum_k |a_ik b_kj| (test_linear_elementwise_error; operands with a wide dynamic range:
+tests/test_dense_range_gpu.py).  All three accumulate in float32; for the deepest reductions used here (K = 1024
+forward, batch = 8192 in the weight gradient) that rounding stays below the bound."""
 import numpy as np
 import pytest
 import torch
@@ -403,3 +405,39 @@ def test_f16x2_with_maxima_handed_in_equals_the_measuring_call(M, N, K, gemm_mod
     y2 = ops.linear_forward(x, w, b, True, x_absmax=ax * 900.0, w_absmax=aw * 3.0)
     ref = torch.relu(x.double() @ w.double().t() + b.double())
     assert ((y2.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 479), (8192, 512, 512), (16421, 256, 1024), (32768, 128, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear_with_presplit_weights(oracle, M, N, K, relu, gemm_mode):
+    """f16x2 with the weight matrix cut into its f16 planes beforehand (dlrm_split_weights): the forward and
+    backward-data products through the kernel that reads the planes (grids of 256 tiles and more: ragged rows, a
+    partial last reduction step, a partial last column tile, bias / ReLU / ReLU mask fused) against the oracle,
+    element by element, and against the same products with the split inside the kernel."""
+    from dlrm_amd import ops
+    if gemm_mode != 2:
+        pytest.skip("the planes belong to the f16x2 evaluation")
+    rng = np.random.default_rng(M + N + K)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dz = (rng.standard_normal((M, N)) * (rng.random((M, N)) > 0.5)).astype(np.float32)
+    y_ref = oracle.linear_forward(x, w, b, relu)
+    dx_ref, _, _ = oracle.linear_backward(x, w, np.ones_like(y_ref), dz, False)
+    dxm_ref = dx_ref * (x > 0)
+    d_x, d_w, d_dz, d_b = padded(x, 32), padded(w), padded(dz), torch.from_numpy(b).cuda()
+    sw = ops.SplitWeights(d_w)
+    y = ops.linear_forward(d_x, d_w, d_b, relu, w_planes=sw)
+    y_in = ops.linear_forward(d_x, d_w, d_b, relu)
+    dx = ops.linear_backward_data(d_dz, d_w, w_planes=sw)
+    dxm = ops.linear_backward_data(d_dz, d_w, relu_mask=d_x, w_planes=sw)
+    dx_in = ops.linear_backward_data(d_dz, d_w)
+    torch.cuda.synchronize()
+    ax, aw, adz = np.abs(x).astype(np.float64), np.abs(w).astype(np.float64), np.abs(dz).astype(np.float64)
+    assert rel_err(y.cpu().numpy(), y_ref) <= 1e-5 and rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5
+    assert rel_err(dxm.cpu().numpy(), dxm_ref) <= 1e-5
+    assert elementwise_excess(y.cpu().numpy(), y_ref, ax @ aw.T + np.abs(b)[None, :]) <= 8.0
+    assert elementwise_excess(dx.cpu().numpy(), dx_ref, adz @ aw) <= 8.0
+    # same pieces, same products, another order of the float32 accumulation: a few ulps of the absolute sum apart
+    assert elementwise_excess(y.cpu().numpy(), y_in.cpu().numpy().astype(np.float64), ax @ aw.T + np.abs(b)[None, :]) <= 8.0
+    assert elementwise_excess(dx.cpu().numpy(), dx_in.cpu().numpy().astype(np.float64), adz @ aw) <= 8.0

@@ -23,16 +23,22 @@ from tests.test_dense_gpu import elementwise_excess, padded
 
 pytestmark = pytest.mark.gpu
 
-M, N, K = 1024, 384, 479
+N, K = 384, 479
+M = 1024            # rebound per test: the kernel that reads pre-split weights only takes grids of 256 tiles and more
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["f32mfma", "bf16x3", "f16x2"], autouse=True)
+@pytest.fixture(params=[0, 1, 2, 3], ids=["f32mfma", "bf16x3", "f16x2", "f16x2-planes"], autouse=True)
 def gemm_mode(request):
+    """3: f16x2 with the weights split beforehand (dlrm_split_weights), the forward and backward-data products through
+    the kernel that reads those planes -- on a batch large enough for that kernel to be chosen"""
+    global M
     from dlrm_amd import ops
     old = ops.get_gemm_mode()
-    ops.set_gemm_mode(request.param)
+    ops.set_gemm_mode(min(request.param, 2))
+    M = 11008 if request.param == 3 else 1024
     yield request.param
     ops.set_gemm_mode(old)
+    M = 1024
 
 
 def base_operands(seed):
@@ -72,14 +78,15 @@ def make_case(name):
     return x, w, dz
 
 
-def products(oracle, x, w, dz):
+def products(oracle, x, w, dz, planes=False):
     from dlrm_amd import ops
     b = np.zeros(N, np.float32)
     y_ref = oracle.linear_forward(x, w, b, False)
     dx_ref, dw_ref, db_ref = oracle.linear_backward(x, w, y_ref, dz, False)
-    d_x, d_w, d_dz = padded(x), padded(w), padded(dz)
-    y = ops.linear_forward(d_x, d_w, torch.from_numpy(b).cuda(), False)
-    dx = ops.linear_backward_data(d_dz, d_w)
+    d_x, d_w, d_dz = padded(x, 32), padded(w), padded(dz)
+    kw = dict(w_planes=ops.SplitWeights(d_w)) if planes else {}
+    y = ops.linear_forward(d_x, d_w, torch.from_numpy(b).cuda(), False, **kw)
+    dx = ops.linear_backward_data(d_dz, d_w, **kw)
     dw, db, _ = ops.linear_backward_weight(d_dz, d_x)
     torch.cuda.synchronize()
     got = {"y": y.cpu().numpy(), "dx": dx.cpu().numpy(), "dw": dw.cpu().numpy(), "db": db.cpu().numpy()}
@@ -96,7 +103,7 @@ CASES = ["sample_1e4", "sample_1e7", "feature_1e4", "feature_1e7", "dz_lognormal
 @pytest.mark.parametrize("case", CASES)
 def test_wide_range_operands_elementwise(oracle, case, gemm_mode):
     x, w, dz = make_case(case)
-    got, ref, scale, _ = products(oracle, x, w, dz)
+    got, ref, scale, _ = products(oracle, x, w, dz, planes=gemm_mode == 3)
     worst = {k: elementwise_excess(got[k], ref[k], scale[k]) for k in got}
     print("gemm mode %d  %-16s excess in units of 2^-24*abs-sum: %s" % (gemm_mode, case, worst))
     assert all(np.isfinite(got[k]).all() for k in got)
@@ -111,8 +118,8 @@ def test_rows_far_below_the_tensor_maximum(oracle, factor, gemm_mode):
     _, x, w, dz = base_operands(int(-np.log10(factor)))
     x[100:228] *= factor
     dz[100:228] *= factor
-    got, ref, scale, (ax, aw, adz) = products(oracle, x, w, dz)
-    if gemm_mode == 2:
+    got, ref, scale, (ax, aw, adz) = products(oracle, x, w, dz, planes=gemm_mode == 3)
+    if gemm_mode >= 2:
         fl = 2.0 ** -48 / 2.0 ** -24 / 8.0      # the floor in the units elementwise_excess divides by, for a limit of 8
         scale["y"] = scale["y"] + fl * (ax.max() * aw.sum(1)[None, :] + aw.max() * ax.sum(1)[:, None])
         scale["dx"] = scale["dx"] + fl * (adz.max() * aw.sum(0)[None, :] + aw.max() * adz.sum(1)[:, None])

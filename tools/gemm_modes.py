@@ -27,7 +27,8 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    names = {0: "f32 MFMA", 1: "bf16x3", 2: "f16x2+pass", 3: "f16x2"}
+    names = {0: "f32 MFMA", 1: "bf16x3", 2: "f16x2+pass", 3: "f16x2", 4: "f16x2+planes"}
+    only = [int(v) for v in os.environ.get("GEMM_MODES_ONLY", "0,1,2,3,4").split(",")]
     records = []
     for N, K in ((1024, 479), (1024, 1024), (512, 1024), (256, 512)):
         Kp = (K + 3) // 4 * 4
@@ -44,11 +45,15 @@ def main():
         dx64 = (dz[rows].double() @ w.double()) * (x[rows] > 0)
         dw64 = dz.double().t() @ x.double()
         ax, aw, adz = x.abs().max().reshape(1), w.abs().max().reshape(1), dz.abs().max().reshape(1)
-        for mode in (0, 1, 2, 3):      # 3: f16x2 with the operands' maxima handed in (no measuring passes)
+        sw = ops.SplitWeights(w)
+        for mode in only:      # 3: f16x2 with the operands' maxima handed in (no measuring passes); 4: and the weights pre-split
             ops.set_gemm_mode(min(mode, 2))
-            kf = dict(x_absmax=ax, w_absmax=aw) if mode == 3 else {}
-            kd = dict(dz_absmax=adz, w_absmax=aw) if mode == 3 else {}
-            kw = dict(dz_absmax=adz, x_absmax=ax) if mode == 3 else {}
+            kf = dict(x_absmax=ax, w_absmax=aw) if mode >= 3 else {}
+            kd = dict(dz_absmax=adz, w_absmax=aw) if mode >= 3 else {}
+            kw = dict(dz_absmax=adz, x_absmax=ax) if mode >= 3 else {}
+            if mode == 4:
+                kf["w_planes"] = sw
+                kd["w_planes"] = sw
             t_f = timeit(lambda: ops.linear_forward(x, w, b, relu=True, out=y, **kf))
             e_f = ((y[rows].double() - y64).abs().max() / y64.abs().max()).item()
             t_d = timeit(lambda: ops.linear_backward_data(dz, w, relu_mask=x, out=dx, **kd))
@@ -75,7 +80,8 @@ def main():
         json.dump({"command": "python tools/gemm_modes.py %d <this file>" % M,
                    "note": "one layer at a time, operands N(0,1) (x after ReLU, dz 1e-5 N(0,1) with half the entries "
                            "zero), 20 timed calls each; errors against float64 products (forward / backward-data on 2048 rows); "
-                           "'f16x2+pass': the call measures both operands' maxima itself, 'f16x2': maxima handed in",
+                           "'f16x2+pass': the call measures both operands' maxima itself, 'f16x2': maxima handed in, "
+                           "'f16x2+planes': and the weight matrix split into its f16 planes beforehand (dlrm_split_weights)",
                    "layers": records}, open(sys.argv[2], "w"), indent=1)
 
 
