@@ -832,14 +832,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams 
 // (A = x, B = W) and backward-data (A = dz, B = W^T, planes of the transposed matrix) products of the big layers.
 //
 // 128 x 128 outputs per 256-thread workgroup, 32-deep reduction steps.  Wave w owns rows 32w .. 32w+31 and all 128
-// columns (4 MFMA tiles of 32 x 32, two accumulators each: see split2_pair).  The A operand never touches LDS:
-// lane (row r, half h) of a wave reads ITS 16 reduction elements of the step -- 64 contiguous bytes of row r -- from
-// global memory, splits them in registers and uses the pieces as its MFMA A fragments (first 8 elements in the first
-// of the step's two 16-deep MFMA slices, the other 8 in the second: the reduction index of MFMA position (h, j) of
-// slice s is 16 h + 8 s + j, and the B planes are read from LDS in the same order).  So A costs no LDS write, no
-// fragment read and waits for no barrier; only the B planes (16 KB per step: 128 x 32 f16, two planes) go through a
-// two-stage LDS ring, one barrier per step.  Against gemm_split_kernel<.., 2>: half the split arithmetic (A only, and
-// every A element is split by exactly one lane), a quarter of the LDS write instructions, half the barriers.
+// columns (4 MFMA tiles of 32 x 32, two accumulators each: see split2_pair).  Nobody but that wave needs its A rows:
+// they arrive as raw float32 in a wave-private piece of LDS (direct-to-LDS loads, coalesced), lane (row r, half h)
+// reads ITS 16 reduction elements of the step -- 64 bytes of row r -- back, splits them in registers and uses the
+// pieces as its MFMA A fragments (first 8 elements in the first of the step's two 16-deep MFMA slices, the other 8 in
+// the second: the reduction index of MFMA position (h, j) of slice s is 16 h + 8 s + j, and the B planes are read in
+// the same order).  So A waits for no barrier and every A element is split by exactly one lane; only the B planes
+// (16 KB per step: 128 x 32 f16, two planes) are shared, in a two-stage ring with one barrier per step.  No operand
+// passes through registers on its way to LDS.  Against gemm_split_kernel<.., 2>: half the split arithmetic, no LDS
+// write instructions, half the barriers.  (Reading A straight from global memory into the fragments was measured
+// first: every lane of such a load is on another row, i.e. another cache line, and the loads took four times the
+// address cycles of coalesced ones -- no faster than the kernel it was to replace.)
 //   LDS image of a plane: [128][32] f16, 64-byte rows whose 16-byte chunks are XOR-swizzled with bits 2..3 of the row
 //   (conflict-free ds_write_b128 of the incoming pieces and ds_read_b128 of the fragments)
 constexpr int kPStage = 2 * 128 * 64;       // bytes per stage: h plane, l plane
@@ -873,7 +876,7 @@ __device__ inline void f16p_split(const f32x4 (&r)[4], float scale, int k_left, 
 // step's split (about 80 vector operations) spread behind the MFMAs
 template <int I>
 __device__ inline void f16p_interleave() {
-    if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
     if constexpr (I < 24) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         // the second slice's fragments of column tile k once the first slice's MFMAs on that tile have issued
@@ -885,13 +888,19 @@ __device__ inline void f16p_interleave() {
 
 template <bool TAIL>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p) {
-    constexpr int kOutStaging = 4 * 32 * (64 + 4) * 4;    // the epilogue parks 32 x 64 per wave at a time
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage > kOutStaging ? 2 * kPStage : kOutStaging];
+    // LDS: two stages of B planes (16 KB each, shared by the four waves), then two stages of raw float32 A rows
+    // (16 KB each: 4 KB per wave, read only by the wave that fetched them)
+    constexpr int kAStage = 4 * 32 * 128, kAOff = 2 * kPStage;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage + 2 * kAStage];
+    static_assert(2 * kPStage + 2 * kAStage >= 4 * 32 * (64 + 4) * 4, "the epilogue parks 32 x 64 per wave at a time");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
     const float scale_a = split2_scale(__float_as_uint(*p.a_max));
     const float scale_b = split2_scale(__float_as_uint(*p.b_max));
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    (void)tid;
     const int nwg = p.gx * p.gy;
     const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
@@ -899,21 +908,30 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     const int m0 = by * 128, n0 = bx * 128;
     const int steps = (p.K + 31) / 32;
 
-    // A: this lane's row (clamped: surplus rows only feed outputs that are never stored) and its 64 bytes of a step
-    const int row = m0 + 32 * wave + l31;
-    const int rowc = row < p.M ? row : p.M - 1;
+    // A: a step of this wave's 32 rows is 4 KB of float32 (128 bytes per row), fetched by four direct-to-LDS loads of
+    // 8 rows each.  Within one load 8 consecutive lanes cover one row's 128 bytes (coalesced), in an order that leaves
+    // chunk c of row r at position c ^ ((r >> 1) & 7) of the row's image: lane (r, half) then reads ITS 64 bytes --
+    // chunks 4 half .. 4 half + 3 -- with four conflict-free ds_read_b128.  Rows past M are clamped (they only feed
+    // outputs that are never stored).
     const float *a_origin = p.A + (int64_t)m0 * p.lda;
-    const unsigned a_off = (unsigned)((rowc - m0) * (int)p.lda + 16 * half) * 4u;
-    // B planes go global -> LDS directly (buffer_load ... lds: 64 lanes x 16 bytes land side by side, 16 rows of the
-    // image per instruction).  Waves 0, 1 bring the h plane's rows 0..63 / 64..127, waves 2, 3 the l plane's, four
+    unsigned a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pr = lane >> 3, pc = lane & 7;
+        const int row = m0 + 32 * wave + 8 * j + pr;
+        const int rowc = row < p.M ? row : p.M - 1;
+        a_off[j] = (unsigned)((rowc - m0) * (int)p.lda * 4 + 16 * (pc ^ (pr >> 1) ^ (4 * (j & 1))));
+    }
+    const int a_lds = kAOff + uwave * 4096;                           // this wave's rows inside an A stage (+ kAStage: other stage)
+    const int a_rd = l31 * 128, a_sw = (l31 >> 1) & 7;
+    // B planes go global -> LDS directly as well (64 lanes x 16 bytes land side by side, 16 rows of the image per
+    // instruction).  Waves 0, 1 bring the h plane's rows 0..63 / 64..127, waves 2, 3 the l plane's, four
     // instructions each; the swizzle is applied on the global side: the lane that fills position pp of row n fetches
     // the row's chunk pp ^ ((n >> 2) & 3).
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 64 * (uwave & 1)) * p.bp_ld;
     const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * ((lane & 3) ^ ((lane >> 4) & 3)));
     const unsigned b_off16 = (unsigned)(16 * (int)p.bp_ld);
-    const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;       // this wave's 4 KB of a stage
-    (void)tid;
+    const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;       // this wave's 4 KB of a B stage
     const int rd0 = bp_lds_off(l31, 2 * half), rd1 = bp_lds_off(l31, 2 * half + 1);   // slice 0 / 1, + 2048 per column tile
 
     f32x16 hi[4], lo[4];
@@ -922,22 +940,27 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; r++) { hi[ni][r] = 0.f; lo[ni][r] = 0.f; }
 
-    auto load_a = [&](int t, f32x4 (&r)[4]) {
+    auto dma_a = [&](int t, int stage) {
         const int tc = t < steps ? t : steps - 1;     // (surplus requests re-read the last step)
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_origin + 32 * tc), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            r[q] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(a_off + 16 * q), 0, 0));
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + a_lds + stage * kAStage + 1024 * j), 16, (int)a_off[j], 0, 0, 0);
     };
-    auto load_b = [&](int t, unsigned char *stage) {
+    auto dma_b = [&](int t, int stage) {
         const int tc = t < steps ? t : steps - 1;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
-        typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(stage + b_lds + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + b_lds + stage * kPStage + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
+    };
+    // this lane's 16 float32 of a step out of the wave's A image
+    auto read_a = [&](int stage, f32x4 (&r)[4]) {
+        const unsigned char *base = smem + a_lds + stage * kAStage + a_rd;
+#pragma unroll
+        for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const f32x4 *>(base + 16 * ((4 * half + q) ^ a_sw));
     };
     // the 24 MFMAs of one step: slice s pairs A pieces af[s] with the B fragments at chunk (2 half + s)
     auto mfma_step = [&](const unsigned char *stage, const bf16x8 (&af)[2][2]) {
@@ -957,43 +980,52 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
             }
         }
     };
-    unsigned char *const s0 = smem, *const s1 = smem + kPStage;
-    f32x4 ra[4], rb[4];           // raw A of two steps in turn
+
     bf16x8 fa[2][2], fb[2][2];    // A pieces of two steps in turn
-    // step t: MFMAs on (stage_c, f_c); meanwhile raw_n (step t+1, requested one step ago) is split into f_n, the B
-    // pieces of step t+1 go to stage_n, and step t+2's A is requested into raw_c (whose step has been split already)
-    auto step = [&](int t, unsigned char *stage_c, unsigned char *stage_n, f32x4 (&raw_c)[4], f32x4 (&raw_n)[4],
-                    bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
-        load_b(t + 1, stage_n);        // (every wave has passed the barrier behind its last read of stage_n)
-        load_a(t + 2, raw_c);
+    // step t (parity par): MFMAs on (B stage par, f_c); meanwhile the raw A of step t+1 (A stage par^1, requested one
+    // step ago) is read and split into f_n, the B planes of step t+1 travel to B stage par^1, the A rows of step t+2 to
+    // A stage par (whose rows were split during the previous step)
+    auto step = [&](int t, int par, bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
+        dma_b(t + 1, par ^ 1);        // (every wave has passed the barrier behind its last read of that stage)
+        dma_a(t + 2, par);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; q++) pin_here(raw_n[q]);
-        f16p_split<TAIL>(raw_n, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
-        mfma_step(stage_c, f_c);
+        __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8): the A rows of step t+1 have landed (the eight requests above may be in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 raw[4];
+        read_a(par ^ 1, raw);
+        f16p_split<TAIL>(raw, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
+        mfma_step(smem + par * kPStage, f_c);
         f16p_interleave<0>();
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's pieces of stage_n have landed (the four A requests issued behind them may stay in flight)
+        // this wave's pieces of the next B stage have landed (the four A requests issued behind them may stay in flight)
         __builtin_amdgcn_s_waitcnt(0x0F74);
         __syncthreads();
     };
-    load_a(0, ra);
-    load_b(0, s0);
-    load_a(1, rb);
-    f16p_split<TAIL>(ra, scale_a, p.K - 16 * half, fa);
+    dma_a(0, 0);
+    dma_b(0, 0);
+    dma_a(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F74);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x4 raw[4];
+        read_a(0, raw);
+        f16p_split<TAIL>(raw, scale_a, p.K - 16 * half, fa);
+    }
     __syncthreads();
     // pairs of steps, no branch inside the loop (control flow that merges the 128 accumulator registers of several
     // step bodies costs copies and spills); an odd last step follows it
     int t = 0;
     for (; t + 1 < steps; t += 2) {
-        step(t, s0, s1, ra, rb, fa, fb);
-        step(t + 1, s1, s0, rb, ra, fb, fa);
+        step(t, 0, fa, fb);
+        step(t + 1, 1, fb, fa);
     }
-    if (t < steps) step(t, s0, s1, ra, rb, fa, fb);
+    if (t < steps) step(t, 0, fa, fb);
 
     const float inv_a = 1.0f / scale_a, inv_b = 1.0f / scale_b;
     float *fsm = reinterpret_cast<float *>(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // (surplus A requests must not land in the epilogue's staging area)
+    __syncthreads();
 #pragma unroll
     for (int hn = 0; hn < 2; hn++) {      // two column halves of 64: mixed terms in, operand scales out, then the usual epilogue
         f32x16 o[1][2];
