@@ -874,7 +874,7 @@ __device__ inline void f16p_split(const f32x4 (&r)[4], float scale, int k_left, 
 
 // scheduling recipe of a step: the 16 fragment reads early (8 up front, the rest behind the first MFMAs), the next
 // step's split (about 80 vector operations) spread behind the MFMAs
-template <int I>
+template <int I, int WRITES>
 __device__ inline void f16p_interleave() {
     if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
     if constexpr (I < 24) {
@@ -882,11 +882,15 @@ __device__ inline void f16p_interleave() {
         // the second slice's fragments of column tile k once the first slice's MFMAs on that tile have issued
         if constexpr (I < 12 && I % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, I < 8 ? 3 : 4, 0);
-        f16p_interleave<I + 1>();
+        // LDS writes of the register path, one behind each of the last MFMAs
+        if constexpr (WRITES > 0 && I >= 24 - WRITES) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        f16p_interleave<I + 1, WRITES>();
     }
 }
 
-template <bool TAIL>
+// ADMA / BDMA: the A rows / B planes travel global -> LDS directly; else through registers (coalesced 16-byte loads at
+// the start of a step, ds_write_b128 at its end)
+template <bool TAIL, bool ADMA, bool BDMA>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p) {
     // LDS: two stages of B planes (16 KB each, shared by the four waves), then two stages of raw float32 A rows
     // (16 KB each: 4 KB per wave, read only by the wave that fetched them)
@@ -920,8 +924,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
         const int pr = lane >> 3, pc = lane & 7;
         const int row = m0 + 32 * wave + 8 * j + pr;
         const int rowc = row < p.M ? row : p.M - 1;
-        a_off[j] = (unsigned)((rowc - m0) * (int)p.lda * 4 + 16 * (pc ^ (pr >> 1) ^ (4 * (j & 1))));
+        a_off[j] = (unsigned)((rowc - m0) * (int)p.lda * 4 + 16 * (ADMA ? (pc ^ (pr >> 1) ^ (4 * (j & 1))) : pc));
     }
+    // (register path: lane (pr, pc) of load j holds chunk pc of row 8 j + pr and writes it to position pc ^ ((row >> 1) & 7))
+    const int a_wr = (lane >> 3) * 128 + 16 * ((lane & 7) ^ ((lane >> 4) & 3));       // + 1024 j, and ^ 64 for odd j
     const int a_lds = kAOff + uwave * 4096;                           // this wave's rows inside an A stage (+ kAStage: other stage)
     const int a_rd = l31 * 128, a_sw = (l31 >> 1) & 7;
     // B planes go global -> LDS directly as well (64 lanes x 16 bytes land side by side, 16 rows of the image per
@@ -929,7 +935,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     // instructions each; the swizzle is applied on the global side: the lane that fills position pp of row n fetches
     // the row's chunk pp ^ ((n >> 2) & 3).
     const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 64 * (uwave & 1)) * p.bp_ld;
-    const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * ((lane & 3) ^ ((lane >> 4) & 3)));
+    const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * (BDMA ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)));
+    const int b_wr = (lane >> 2) * 64 + 16 * ((lane & 3) ^ ((lane >> 4) & 3));        // + 1024 j (register path)
     const unsigned b_off16 = (unsigned)(16 * (int)p.bp_ld);
     const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;       // this wave's 4 KB of a B stage
     const int rd0 = bp_lds_off(l31, 2 * half), rd1 = bp_lds_off(l31, 2 * half + 1);   // slice 0 / 1, + 2048 per column tile
@@ -955,6 +962,30 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
 #pragma unroll
         for (int j = 0; j < 4; j++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + b_lds + stage * kPStage + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
+    };
+    // register path: request now, write to the image later
+    auto load_a = [&](int t, u32x4 (&r)[4]) {
+        const int tc = t < steps ? t : steps - 1;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_origin + 32 * tc), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)a_off[j], 0, 0);
+    };
+    auto store_a = [&](int stage, const u32x4 (&r)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<u32x4 *>(smem + a_lds + stage * kAStage + 1024 * j + (a_wr ^ (64 * (j & 1)))) = r[j];
+    };
+    auto load_b = [&](int t, u32x4 (&r)[4]) {
+        const int tc = t < steps ? t : steps - 1;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(b_off + j * b_off16), 0, 0);
+    };
+    auto store_b = [&](int stage, const u32x4 (&r)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4 *>(smem + b_lds + stage * kPStage + 1024 * j + b_wr) = r[j];
     };
     // this lane's 16 float32 of a step out of the wave's A image
     auto read_a = [&](int stage, f32x4 (&r)[4]) {
@@ -982,30 +1013,42 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     };
 
     bf16x8 fa[2][2], fb[2][2];    // A pieces of two steps in turn
-    // step t (parity par): MFMAs on (B stage par, f_c); meanwhile the raw A of step t+1 (A stage par^1, requested one
-    // step ago) is read and split into f_n, the B planes of step t+1 travel to B stage par^1, the A rows of step t+2 to
-    // A stage par (whose rows were split during the previous step)
+    u32x4 ast[4], bst[4];         // register path: an operand's pieces between their loads and their LDS writes
+    // step t (parity par): MFMAs on (B stage par, f_c); meanwhile the raw A of step t+1 (A stage par^1) is read and
+    // split into f_n, the B planes of step t+1 travel to B stage par^1, the A rows of step t+2 to A stage par (whose
+    // rows were split during the previous step)
     auto step = [&](int t, int par, bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
-        dma_b(t + 1, par ^ 1);        // (every wave has passed the barrier behind its last read of that stage)
-        dma_a(t + 2, par);
+        if constexpr (BDMA) dma_b(t + 1, par ^ 1);        // (every wave has passed the barrier behind its last read of that stage)
+        else load_b(t + 1, bst);
+        if constexpr (ADMA) dma_a(t + 2, par);
+        else load_a(t + 2, ast);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F78);      // vmcnt(8): the A rows of step t+1 have landed (the eight requests above may be in flight)
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ADMA) {
+            // the A rows of step t+1 have landed (requests issued since then may be in flight: 8 here, fewer if B
+            // goes through registers -- those are counted by the compiler's own waits)
+            __builtin_amdgcn_s_waitcnt(BDMA ? 0x0F78 : 0x0F78);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x4 raw[4];
         read_a(par ^ 1, raw);
         f16p_split<TAIL>(raw, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
         mfma_step(smem + par * kPStage, f_c);
-        f16p_interleave<0>();
+        if constexpr (!BDMA) store_b(par ^ 1, bst);
+        if constexpr (!ADMA) store_a(par, ast);
+        f16p_interleave<0, (BDMA ? 0 : 4) + (ADMA ? 0 : 4)>();
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's pieces of the next B stage have landed (the four A requests issued behind them may stay in flight)
-        __builtin_amdgcn_s_waitcnt(0x0F74);
+        // this wave's pieces of the next B stage have landed (A requests issued behind them may stay in flight)
+        if constexpr (BDMA) __builtin_amdgcn_s_waitcnt(0x0F74);
         __syncthreads();
     };
-    dma_a(0, 0);
-    dma_b(0, 0);
-    dma_a(1, 1);
+    if constexpr (ADMA) dma_a(0, 0); else load_a(0, ast);
+    if constexpr (BDMA) dma_b(0, 0); else load_b(0, bst);
+    if constexpr (!ADMA) store_a(0, ast);
+    if constexpr (!BDMA) store_b(0, bst);
+    if constexpr (ADMA) dma_a(1, 1);
+    else { load_a(1, ast); store_a(1, ast); }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F74);
+    if constexpr (ADMA || BDMA) __builtin_amdgcn_s_waitcnt(ADMA ? 0x0F74 : 0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     {
         f32x4 raw[4];
@@ -1377,8 +1420,22 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
         base += 4 * d.f_rows * d.f_ld;
         p.bp_h = base; p.bp_l = base + 2 * d.t_rows * d.t_ld; p.bp_ld = 2 * d.t_ld;
     }
-    if (p.K % 32 != 0) hipLaunchKernelGGL(gemm_f16p_kernel<true>, dim3((unsigned)(p.gx * p.gy)), dim3(kGemmThreads), 0, s, p);
-    else hipLaunchKernelGGL(gemm_f16p_kernel<false>, dim3((unsigned)(p.gx * p.gy)), dim3(kGemmThreads), 0, s, p);
+    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes global -> LDS directly instead of through registers
+    static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? atoi(e) & 3 : 0; }();
+    const dim3 grid((unsigned)(p.gx * p.gy)), block(kGemmThreads);
+    const bool tail = p.K % 32 != 0;
+#define DLRM_F16P_LAUNCH(A, B)                                                                  \
+    do {                                                                                        \
+        if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B>), grid, block, 0, s, p);     \
+        else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B>), grid, block, 0, s, p);         \
+    } while (0)
+    switch (path) {
+    case 0: DLRM_F16P_LAUNCH(false, false); break;
+    case 1: DLRM_F16P_LAUNCH(true, false); break;
+    case 2: DLRM_F16P_LAUNCH(false, true); break;
+    default: DLRM_F16P_LAUNCH(true, true); break;
+    }
+#undef DLRM_F16P_LAUNCH
     DLRM_LAUNCH_CHECK();
     *done = true;
     return DLRM_OK;
