@@ -29,6 +29,16 @@ int validate_embbag(const dlrm_embbag *e);
 
 constexpr int kBwdThreads = 256;
 
+#ifdef DLRM_PK_PROBE
+// Diagnostic build only (tools/build_pk_probe.sh; never part of dlrm_amd/lib): every accumulation of the update is
+// recomputed with one scalar v_fma_f32 on the same registers; where the two disagree the operands, both results and
+// the gradient element read from memory once more are recorded.  Tells a packed instruction that returned a wrong
+// half from an operand register that did not hold the loaded value yet.
+constexpr int kProbeRecords = 256;
+__device__ unsigned g_pk_probe_count;
+__device__ unsigned g_pk_probe[kProbeRecords][12];
+#endif
+
 template <typename KEY>
 struct WsLayout {
     KEY *keys_in, *keys_out;
@@ -430,7 +440,30 @@ __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p,
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
-                for (int q = 0; q < NF; q++) acc[c][q] = accumulate ? acc[c][q] + g[u][c][q] * sc[u] : g[u][c][q] * sc[u];
+                for (int q = 0; q < NF; q++) {
+#ifdef DLRM_PK_PROBE
+                    const float before = acc[c][q];
+#endif
+                    acc[c][q] = accumulate ? acc[c][q] + g[u][c][q] * sc[u] : g[u][c][q] * sc[u];
+#ifdef DLRM_PK_PROBE
+                    if (accumulate && col_ok[c]) {
+                        float ref;
+                        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ref) : "v"(g[u][c][q]), "v"(sc[u]), "v"(before));
+                        if (__float_as_uint(ref) != __float_as_uint(acc[c][q])) {
+                            const unsigned slot = atomicAdd(&g_pk_probe_count, 1u);
+                            if (slot < (unsigned)kProbeRecords) {
+                                const float again = __builtin_nontemporal_load(gp[u] + col[c] + q);
+                                unsigned *r = g_pk_probe[slot];
+                                r[0] = blockIdx.x; r[1] = threadIdx.x; r[2] = (unsigned)(c0 + u); r[3] = (unsigned)q;
+                                r[4] = __float_as_uint(g[u][c][q]); r[5] = __float_as_uint(again);
+                                r[6] = __float_as_uint(sc[u]); r[7] = __float_as_uint(before);
+                                r[8] = __float_as_uint(acc[c][q]); r[9] = __float_as_uint(ref);
+                                r[10] = (unsigned)any_w; r[11] = (unsigned)ext;
+                            }
+                        }
+                    }
+#endif
+                }
             if (!endr[u]) continue;
             if (ext) {                       // the run started in an earlier group: hand the piece over
                 put_piece(grp, 0, acc);
@@ -727,3 +760,16 @@ extern "C" int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_g
                                           dlrm_stream_t stream) {
     return backward_phases(e, d_grad, grad_ld, opt, d_workspace, workspace_bytes, 2, stream);
 }
+
+#ifdef DLRM_PK_PROBE
+// diagnostic build only: number of disagreements since the last call and the first records (12 words each)
+extern "C" int dlrm_pk_probe_read(unsigned *h_count, unsigned *h_records, int max_records) {
+    DLRM_HIP(hipDeviceSynchronize());
+    DLRM_HIP(hipMemcpyFromSymbol(h_count, HIP_SYMBOL(dlrm::g_pk_probe_count), sizeof(unsigned)));
+    const int n = max_records < dlrm::kProbeRecords ? max_records : dlrm::kProbeRecords;
+    DLRM_HIP(hipMemcpyFromSymbol(h_records, HIP_SYMBOL(dlrm::g_pk_probe), sizeof(unsigned) * 12 * n));
+    const unsigned zero = 0;
+    DLRM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dlrm::g_pk_probe_count), &zero, sizeof(unsigned)));
+    return DLRM_OK;
+}
+#endif

@@ -845,7 +845,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(GemmParams 
 // address cycles of coalesced ones -- no faster than the kernel it was to replace.)
 //   LDS image of a plane: [128][32] f16, 64-byte rows whose 16-byte chunks are XOR-swizzled with bits 2..3 of the row
 //   (conflict-free ds_write_b128 of the incoming pieces and ds_read_b128 of the fragments)
-constexpr int kPStage = 2 * 128 * 64;       // bytes per stage: h plane, l plane
 
 __device__ inline int bp_lds_off(int n, int c) { return n * 64 + 16 * (c ^ ((n >> 2) & 3)); }
 
@@ -872,26 +871,30 @@ __device__ inline void f16p_split(const f32x4 (&r)[4], float scale, int k_left, 
     }
 }
 
-// scheduling recipe of a step: the 16 fragment reads early (8 up front, the rest behind the first MFMAs), the next
-// step's split (about 80 vector operations) spread behind the MFMAs
-template <int I, int WRITES>
+// scheduling recipe of a step (6 NI MFMAs): the raw A rows and the first slice's fragments of the first four column
+// tiles early, every further pair of fragments once the MFMAs of the tile before it have issued, the next step's split
+// (about 80 vector operations) spread behind the MFMAs, the LDS writes of the register path behind the last ones
+template <int I, int NI, int WRITES>
 __device__ inline void f16p_interleave() {
+    constexpr int kMfma = 6 * NI, kValu = 84;
     if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-    if constexpr (I < 24) {
+    if constexpr (I < kMfma) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        // the second slice's fragments of column tile k once the first slice's MFMAs on that tile have issued
-        if constexpr (I < 12 && I % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, I < 8 ? 3 : 4, 0);
-        // LDS writes of the register path, one behind each of the last MFMAs
-        if constexpr (WRITES > 0 && I >= 24 - WRITES) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        f16p_interleave<I + 1, WRITES>();
+        if constexpr (I % 3 == 2 && I / 3 < 2 * NI - 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (kValu * (I + 1)) / kMfma - (kValu * I) / kMfma, 0);
+        if constexpr (WRITES > 0 && I >= kMfma - WRITES) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        f16p_interleave<I + 1, NI, WRITES>();
     }
 }
 
 // ADMA / BDMA: the A rows / B planes travel global -> LDS directly; else through registers (coalesced 16-byte loads at
 // the start of a step, ds_write_b128 at its end)
-template <bool TAIL, bool ADMA, bool BDMA>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p) {
+// NI: 32-column MFMA tiles per wave (4: 128 x 128 outputs per workgroup, two workgroups per compute unit; 8: 128 x 256,
+// 256 accumulator registers per wave, one workgroup per compute unit -- one wave per SIMD with the whole register file:
+// half the split arithmetic and A traffic per MFMA)
+template <bool TAIL, bool ADMA, bool BDMA, int NI>
+__global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kernel(GemmParams p) {
+    constexpr int kPStage = 4096 * NI;          // bytes per B stage: h plane, l plane, 32 NI rows of 64 bytes each
     // LDS: two stages of B planes (16 KB each, shared by the four waves), then two stages of raw float32 A rows
     // (16 KB each: 4 KB per wave, read only by the wave that fetched them)
     constexpr int kAStage = 4 * 32 * 128, kAOff = 2 * kPStage;
@@ -909,7 +912,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
     const int bx = tile % p.gx, by = tile / p.gx;
-    const int m0 = by * 128, n0 = bx * 128;
+    const int m0 = by * 128, n0 = bx * 32 * NI;
     const int steps = (p.K + 31) / 32;
 
     // A: a step of this wave's 32 rows is 4 KB of float32 (128 bytes per row), fetched by four direct-to-LDS loads of
@@ -931,19 +934,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     const int a_lds = kAOff + uwave * 4096;                           // this wave's rows inside an A stage (+ kAStage: other stage)
     const int a_rd = l31 * 128, a_sw = (l31 >> 1) & 7;
     // B planes go global -> LDS directly as well (64 lanes x 16 bytes land side by side, 16 rows of the image per
-    // instruction).  Waves 0, 1 bring the h plane's rows 0..63 / 64..127, waves 2, 3 the l plane's, four
+    // instruction).  Waves 0, 1 bring the lower / upper half of the h plane's rows, waves 2, 3 of the l plane's, NI
     // instructions each; the swizzle is applied on the global side: the lane that fills position pp of row n fetches
     // the row's chunk pp ^ ((n >> 2) & 3).
-    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 64 * (uwave & 1)) * p.bp_ld;
+    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 16 * NI * (uwave & 1)) * p.bp_ld;
     const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * (BDMA ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)));
     const int b_wr = (lane >> 2) * 64 + 16 * ((lane & 3) ^ ((lane >> 4) & 3));        // + 1024 j (register path)
     const unsigned b_off16 = (unsigned)(16 * (int)p.bp_ld);
-    const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;       // this wave's 4 KB of a B stage
+    const int b_lds = (uwave >> 1) * (2048 * NI) + (uwave & 1) * (1024 * NI);       // this wave's share of a B stage
     const int rd0 = bp_lds_off(l31, 2 * half), rd1 = bp_lds_off(l31, 2 * half + 1);   // slice 0 / 1, + 2048 per column tile
 
-    f32x16 hi[4], lo[4];
+    f32x16 hi[NI], lo[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++)
+    for (int ni = 0; ni < NI; ni++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { hi[ni][r] = 0.f; lo[ni][r] = 0.f; }
 
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NI; j++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + b_lds + stage * kPStage + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
     };
     // register path: request now, write to the image later
@@ -976,16 +979,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
         for (int j = 0; j < 4; j++)
             *reinterpret_cast<u32x4 *>(smem + a_lds + stage * kAStage + 1024 * j + (a_wr ^ (64 * (j & 1)))) = r[j];
     };
-    auto load_b = [&](int t, u32x4 (&r)[4]) {
+    auto load_b = [&](int t, u32x4 (&r)[NI]) {
         const int tc = t < steps ? t : steps - 1;
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 4; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(b_off + j * b_off16), 0, 0);
+        for (int j = 0; j < NI; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(b_off + j * b_off16), 0, 0);
     };
-    auto store_b = [&](int stage, const u32x4 (&r)[4]) {
+    auto store_b = [&](int stage, const u32x4 (&r)[NI]) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4 *>(smem + b_lds + stage * kPStage + 1024 * j + b_wr) = r[j];
+        for (int j = 0; j < NI; j++) *reinterpret_cast<u32x4 *>(smem + b_lds + stage * kPStage + 1024 * j + b_wr) = r[j];
     };
     // this lane's 16 float32 of a step out of the wave's A image
     auto read_a = [&](int stage, f32x4 (&r)[4]) {
@@ -993,16 +996,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
 #pragma unroll
         for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const f32x4 *>(base + 16 * ((4 * half + q) ^ a_sw));
     };
-    // the 24 MFMAs of one step: slice s pairs A pieces af[s] with the B fragments at chunk (2 half + s)
+    // the 6 NI MFMAs of one step: slice s pairs A pieces af[s] with the B fragments at chunk (2 half + s)
     auto mfma_step = [&](const unsigned char *stage, const bf16x8 (&af)[2][2]) {
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const f16x8 ah = __builtin_bit_cast(f16x8, af[s][0]), al = __builtin_bit_cast(f16x8, af[s][1]);
             const int rd = s ? rd1 : rd0;
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++) {
+            for (int ni = 0; ni < NI; ni++) {
                 const f16x8 bh = *reinterpret_cast<const f16x8 *>(stage + rd + ni * 2048);
-                const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 8192 + rd + ni * 2048);
+                const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 2048 * NI + rd + ni * 2048);
                 f32x16 c = lo[ni];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
@@ -1013,7 +1016,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     };
 
     bf16x8 fa[2][2], fb[2][2];    // A pieces of two steps in turn
-    u32x4 ast[4], bst[4];         // register path: an operand's pieces between their loads and their LDS writes
+    u32x4 ast[4], bst[NI];        // register path: an operand's pieces between their loads and their LDS writes
     // step t (parity par): MFMAs on (B stage par, f_c); meanwhile the raw A of step t+1 (A stage par^1) is read and
     // split into f_n, the B planes of step t+1 travel to B stage par^1, the A rows of step t+2 to A stage par (whose
     // rows were split during the previous step)
@@ -1024,9 +1027,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
         else load_a(t + 2, ast);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ADMA) {
-            // the A rows of step t+1 have landed (requests issued since then may be in flight: 8 here, fewer if B
+            // the A rows of step t+1 have landed (requests issued since then may be in flight: NI + 4 here, fewer if B
             // goes through registers -- those are counted by the compiler's own waits)
-            __builtin_amdgcn_s_waitcnt(BDMA ? 0x0F78 : 0x0F78);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (NI + 4));          // vmcnt(NI + 4)
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 raw[4];
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
         mfma_step(smem + par * kPStage, f_c);
         if constexpr (!BDMA) store_b(par ^ 1, bst);
         if constexpr (!ADMA) store_a(par, ast);
-        f16p_interleave<0, (BDMA ? 0 : 4) + (ADMA ? 0 : 4)>();
+        f16p_interleave<0, NI, (BDMA ? 0 : NI) + (ADMA ? 0 : 4)>();
         __builtin_amdgcn_sched_barrier(0);
         // this wave's pieces of the next B stage have landed (A requests issued behind them may stay in flight)
         if constexpr (BDMA) __builtin_amdgcn_s_waitcnt(0x0F74);
@@ -1070,7 +1073,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
     __builtin_amdgcn_s_waitcnt(0x0F70);      // (surplus A requests must not land in the epilogue's staging area)
     __syncthreads();
 #pragma unroll
-    for (int hn = 0; hn < 2; hn++) {      // two column halves of 64: mixed terms in, operand scales out, then the usual epilogue
+    for (int hn = 0; hn < NI / 2; hn++) {      // 64 columns at a time: mixed terms in, operand scales out, then the usual epilogue
         f32x16 o[1][2];
 #pragma unroll
         for (int ni = 0; ni < 2; ni++)
@@ -1082,12 +1085,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16p_kernel(GemmParams p
 }
 
 // ---- the planes gemm_f16p_kernel reads: for a weight matrix W [N,K], its f16 pieces (times the scale of max |W|) as
-// [N rounded up to 128][K rounded up to 32] (forward: reduction over K) and, transposed, [K rounded up to 128][N
+// [N rounded up to 256][K rounded up to 32] (forward: reduction over K) and, transposed, [K rounded up to 256][N
 // rounded up to 32] (backward-data: reduction over N), zero in the padding.  Layout of the buffer: forward h, forward
 // l, transposed h, transposed l.
 struct PlaneDims { int64_t f_rows, f_ld, t_rows, t_ld; };     // rows and leading dimension (f16 elements) of the two images
 static PlaneDims plane_dims(int N, int K) {
-    return PlaneDims{ceil_div(N, 128) * 128, ceil_div(K, 32) * 32, ceil_div(K, 128) * 128, ceil_div(N, 32) * 32};
+    return PlaneDims{ceil_div(N, 256) * 256, ceil_div(K, 32) * 32, ceil_div(K, 256) * 256, ceil_div(N, 32) * 32};
 }
 static size_t plane_bytes_total(int N, int K) {
     const PlaneDims d = plane_dims(N, K);
@@ -1411,7 +1414,13 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
                  "w_planes do not belong to this layer's weight matrix");
     const int64_t k32 = ceil_div(p.K, 32) * 32;
     if (!p.a_vec || (p.K % 32 != 0 && p.lda < k32)) return DLRM_OK;
-    p.gx = (int)ceil_div(p.N, 128); p.gy = (int)ceil_div(p.M, 128); p.gz = 1;
+    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes through registers instead of global -> LDS directly;
+    // DLRM_F16P_WIDE=0: never the 256-column tile
+    static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? atoi(e) & 3 : 0; }();
+    static const bool allow_wide = [] { const char *e = getenv("DLRM_F16P_WIDE"); return !(e && e[0] == '0'); }();
+    // 128 x 256 tiles (one workgroup per compute unit) when they still give every compute unit a workgroup
+    const bool wide = allow_wide && p.N > 128 && ceil_div(p.N, 256) * ceil_div(p.M, 128) >= kTileWgs;
+    p.gx = (int)ceil_div(p.N, wide ? 256 : 128); p.gy = (int)ceil_div(p.M, 128); p.gz = 1;
     if ((int64_t)p.gx * p.gy < kTileWgs) return DLRM_OK;
     const PlaneDims d = plane_dims(wp->N, wp->K);
     const unsigned char *base = static_cast<const unsigned char *>(wp->d_planes);
@@ -1420,20 +1429,23 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
         base += 4 * d.f_rows * d.f_ld;
         p.bp_h = base; p.bp_l = base + 2 * d.t_rows * d.t_ld; p.bp_ld = 2 * d.t_ld;
     }
-    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes global -> LDS directly instead of through registers
-    static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? atoi(e) & 3 : 0; }();
     const dim3 grid((unsigned)(p.gx * p.gy)), block(kGemmThreads);
     const bool tail = p.K % 32 != 0;
-#define DLRM_F16P_LAUNCH(A, B)                                                                  \
-    do {                                                                                        \
-        if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B>), grid, block, 0, s, p);     \
-        else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B>), grid, block, 0, s, p);         \
+#define DLRM_F16P_LAUNCH(A, B)                                                                         \
+    do {                                                                                               \
+        if (wide) {                                                                                    \
+            if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 8>), grid, block, 0, s, p);     \
+            else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 8>), grid, block, 0, s, p);         \
+        } else {                                                                                       \
+            if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4>), grid, block, 0, s, p);     \
+            else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4>), grid, block, 0, s, p);         \
+        }                                                                                              \
     } while (0)
     switch (path) {
-    case 0: DLRM_F16P_LAUNCH(false, false); break;
-    case 1: DLRM_F16P_LAUNCH(true, false); break;
-    case 2: DLRM_F16P_LAUNCH(false, true); break;
-    default: DLRM_F16P_LAUNCH(true, true); break;
+    case 0: DLRM_F16P_LAUNCH(true, true); break;
+    case 1: DLRM_F16P_LAUNCH(false, true); break;
+    case 2: DLRM_F16P_LAUNCH(true, false); break;
+    default: DLRM_F16P_LAUNCH(false, false); break;
     }
 #undef DLRM_F16P_LAUNCH
     DLRM_LAUNCH_CHECK();

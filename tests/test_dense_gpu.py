@@ -407,7 +407,8 @@ def test_f16x2_with_maxima_handed_in_equals_the_measuring_call(M, N, K, gemm_mod
     assert ((y2.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 512, 479), (8192, 512, 512), (16421, 256, 1024), (32768, 128, 256)])
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 479), (8192, 512, 512), (16421, 256, 1024), (32768, 128, 256),
+                                   (32768, 512, 479), (32805, 300, 256)])    # (the last two: 256-column tiles)
 @pytest.mark.parametrize("relu", [False, True])
 def test_linear_with_presplit_weights(oracle, M, N, K, relu, gemm_mode):
     """f16x2 with the weight matrix cut into its f16 planes beforehand (dlrm_split_weights): the forward and
