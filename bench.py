@@ -47,7 +47,7 @@ GEMM_CHOICES = {
     "bf16x3": (2, "gemm_split_kernel<3 bf16 pieces>", BF16X3_PEAK, 6.0,
                "float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6",
                "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"),
-    "f16x2": (3, "gemm_split_kernel<2 f16 pieces>", F16X2_PEAK, 3.0,
+    "f16x2": (3, "gemm_f16p_kernel (weights pre-split; weight gradient: gemm_split_kernel<2 f16 pieces>)", F16X2_PEAK, 3.0,
               "float32 product = 3 f16 MFMA terms: peak = 2500 TFLOP/s f16 dense / 3",
               "float32 in/out; products as 3 f16 MFMA terms of 2-way f16 splits of the operands scaled by powers of two, "
               "f32 accumulate (representation error about one float32 ulp per product)"),
@@ -184,6 +184,9 @@ KERNEL_OF = {
     "linear_forward_skinny": "skinny_k_fwd_kernel / gemv_fwd_kernel (13 input columns; one output column)",
     "linear_backward_data_skinny": "gemv_bwd_data_kernel (one output column)",
     "linear_backward_weight_skinny": "skinny_k_bwd_weight_kernel / gemv_bwd_weight_kernel + reduce_slabs",
+    "comm_forward_exchange": "RCCL all-to-all of pooled vectors (reduce-scatter for row-wise tables), peers' arrival included",
+    "comm_backward_exchange": "RCCL all-to-all of their gradients (all-gather for row-wise tables)",
+    "comm_all_reduce": "RCCL all-reduce of the dense gradients (second communicator: beside the backward pass)",
 }
 
 
@@ -292,14 +295,19 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     from dlrm_amd.data import synthetic_batch
     gemm = gemm_choice(args, B)
     gemm_name, gemm_peak = GEMM_CHOICES[gemm][1], GEMM_CHOICES[gemm][2]
-    cm, owner = None, None
+    cm, cm2, owner = None, None, None
     if world == 1 and args.force_exchange:
         cm = dcomm.Comm(dcomm.unique_id(), 0, 1)
+        cm2 = dcomm.Comm(dcomm.unique_id(), 0, 1) if args.two_comms else None
     if world > 1:
         # (--share-gpu: ranks share a device, which RCCL refuses: dlrm_comm's rehearsal transport carries the calls)
-        ids = [(dcomm.unique_id_rehearsal() if args.share_gpu else dcomm.unique_id()) if rank == 0 else None]
+        # --two-comms: RCCL serialises the operations of one communicator; with a second one the all-reduce of the
+        # dense gradients runs beside the backward exchange of the embedding side
+        new_id = dcomm.unique_id_rehearsal if args.share_gpu else dcomm.unique_id
+        ids = [(new_id(), new_id() if args.two_comms else None) if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        cm = dcomm.Comm(ids[0], rank, world)
+        cm = dcomm.Comm(ids[0][0], rank, world)
+        cm2 = None if ids[0][1] is None else dcomm.Comm(ids[0][1], rank, world)
         if args.sharding == "hybrid":
             from dlrm_amd.sharding import plan_hybrid
             owner = plan_hybrid(cfg.table_rows, world, cfg.dim, row_wise_min_rows=args.row_wise_min_rows).owner
@@ -310,7 +318,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
                    overlap=0 if args.no_overlap else (1 if args.overlap else -1), presort=0 if args.no_presort else 1,
                    wgrad_stream={"auto": -1, "on": 1, "off": 0}[args.wgrad_stream], device=dev,
                    gemm_mode=GEMM_CHOICES[gemm][0], one_id_per_bag=gather, force_exchange=args.force_exchange,
-                   graph_steps=args.graph and world == 1)
+                   graph_steps=args.graph and world == 1, comm_dense=cm2)
     if args.graph:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))    # a graph cannot be captured on the NULL stream
     model.init_dense(0)
@@ -373,6 +381,7 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     dt = time.perf_counter() - t0
     if int(model.err_flag.item()) != 0:
         raise SystemExit("out-of-range embedding index reported by the kernels")
+    dt_rank = dt
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -397,6 +406,23 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     for k in kernels:
         k["traffic"] = traffic.get(k["op"]) if traffic else None
     model.enable_timing([], 0)
+    # what every rank saw: its own time for the timed steps, its operator classes and collectives (events on the
+    # streams they run on; a collective's time includes waiting for the slowest peer) and the bytes it exchanges
+    per_rank = None
+    if world > 1 or args.force_exchange:
+        D4 = cfg.dim * 4
+        mine = {"rank": rank, "ms_per_step": dt_rank * 1e3 / args.steps, "whole_tables": Tl, "row_wise_tables": Trw,
+                "exchange_bytes_per_step": {
+                    "forward_all_to_all_sent": Bg * Tl * D4, "backward_all_to_all_sent": Bg * Tl * D4,
+                    "of_which_leave_the_gpu": Bg * Tl * D4 * (world - 1) // world,
+                    "row_wise_reduce_scatter_in": Bg * Trw * D4, "row_wise_all_gather_out": Bg * Trw * D4,
+                    "dense_all_reduce": int(model.info.n_params) * 4},
+                "ms_per_step_by_class": {k["op"]: round(k["ms_per_step"], 4) for k in kernels}}
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
     if roofline is None and kernels:     # (--graph: nothing is bracketed inside a replayed graph)
         roofline = roofline_of(kernels[0], gemm, traffic)
         roofline["timed"] = "HIP events around this operator's launches in %d directly launched steps after the timed region" % n_k
@@ -462,15 +488,21 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
         model.init_dense(0)
         for i in range(args.warmup):
             step(i)
+        model.enable_timing(timed_cls, 16 * args.steps)      # the same class as in the main run, inside the timed steps
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for i in range(args.steps):
             ref_loss = step(args.warmup + i)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
+        ref_rows = kernel_rows(model.collect_timing(), work_for(timed_ids), args.steps, GEMM_CHOICES["bf16x3"][1],
+                               GEMM_CHOICES["bf16x3"][2])
+        ref_roofline = roofline_of(ref_rows[0], "bf16x3", {}) if ref_rows else None
+        if ref_roofline:
+            ref_roofline["timed"] = "HIP events around this operator's launches inside the timed steps"
         exact_ref = {"gemm": GEMM_CHOICES["bf16x3"][5], "value": Bg * args.steps / dt2, "unit": "samples/s",
                      "ms_per_step": dt2 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup,
-                     "loss": float(ref_loss.item()),
+                     "loss": float(ref_loss.item()), "roofline": ref_roofline,
                      "note": "same model, batches, stream options and step count, no operator timing inside the steps.  The "
                              "two losses are not a parity check: with the reference's unscaled N(0,1) layer weights this "
                              "synthetic run is ill-conditioned (the loss of step 1 is in the hundreds) and runs that differ "
@@ -502,10 +534,12 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
             "loss": loss_value, "cache": None, "inference": infer, "roofline": roofline,
             "embbag_hbm_gbps": None if emb is None else emb["achieved"] * 1e3, "embbag_hbm_gbps_from": emb_note,
             "kernels": kernels, "kernels_timed": "every class, in %d extra steps after the timed region" % n_k,
-            "cpu_baseline": cpu_baseline, "exact_split_reference": exact_ref,
+            "cpu_baseline": cpu_baseline, "exact_split_reference": exact_ref, "ranks": per_rank,
         }
         print(json.dumps(line))
     model.close()
+    if cm2 is not None:
+        cm2.close()
     if cm is not None:
         cm.close()
     if world > 1:
@@ -522,6 +556,12 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--row-cap", type=int, default=0, help="cap rows per table (debug on small boxes); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-comms", action="store_true",
+                    help="sharded C-hosted step: a second communicator for the all-reduce of the dense gradients, which then "
+                         "starts behind the top MLP's backward pass and runs beside the backward exchange.  Not the default: "
+                         "two communicators whose kernels wait for peers, on streams that can share a hardware queue (more "
+                         "streams than queues), can end up queued in different orders on different ranks; with one "
+                         "communicator RCCL keeps every rank's operations in issue order")
     ap.add_argument("--no-inference", action="store_true",
                     help="skip the forward-only batches after the train steps (profiler passes that average per launch)")
     ap.add_argument("--sharding", default="table", choices=["table", "hybrid"],

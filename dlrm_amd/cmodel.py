@@ -25,6 +25,7 @@ class ModelConfig(C.Structure):
         ("table_owner", C.POINTER(C.c_int32)), ("force_exchange", C.c_int32),
         ("overlap", C.c_int32), ("presort", C.c_int32), ("wgrad_stream", C.c_int32),
         ("seed", C.c_uint64), ("init_tables", C.c_int32), ("one_id_per_bag", C.c_int32), ("graph_steps", C.c_int32),
+        ("comm_dense", C.c_void_p),
     ]
 
 
@@ -51,11 +52,12 @@ def _view(ptr, shape, dtype, device):
 
 
 class CModel:
-    """cfg: dlrm_amd.model.DLRMConfig.  comm: dlrm_amd.comm.Communicator (sharded runs)."""
+    """cfg: dlrm_amd.model.DLRMConfig.  comm: dlrm_amd.comm.Communicator (sharded runs); comm_dense: a second one over
+    the same ranks for the all-reduce of the dense gradients (it then runs beside the backward exchange)."""
 
     def __init__(self, cfg, batch, rank=0, world=1, comm=None, table_owner=None, seed=0, force_exchange=False,
                  overlap=-1, presort=1, wgrad_stream=-1, idx_dtype=torch.int32, device="cuda", gemm_mode=0,
-                 one_id_per_bag=False, graph_steps=False):
+                 one_id_per_bag=False, graph_steps=False, comm_dense=None):
         self.L = _capi.lib()
         self.cfg, self.B, self.rank, self.world = cfg, batch, rank, world
         self.dev = torch.device(device)
@@ -77,6 +79,8 @@ class CModel:
         c.local_batch, c.rank, c.world = batch, rank, world
         c.comm = comm.h if comm is not None else None
         self._comm = comm
+        c.comm_dense = comm_dense.h if comm_dense is not None else None
+        self._comm_dense = comm_dense
         if table_owner is not None:
             self._owner = (C.c_int32 * T)(*[int(o) for o in table_owner])
             c.table_owner = self._owner
@@ -157,7 +161,8 @@ class CModel:
 
     TIME_CLASSES = ("linear_forward", "linear_backward_data", "linear_backward_weight", "linear_forward_skinny",
                     "linear_backward_data_skinny", "linear_backward_weight_skinny", "embbag_forward",
-                    "embbag_backward_prepare", "embbag_backward_update", "interact_dot_forward", "interact_dot_backward")
+                    "embbag_backward_prepare", "embbag_backward_update", "interact_dot_forward", "interact_dot_backward",
+                    "comm_forward_exchange", "comm_backward_exchange", "comm_all_reduce")
 
     def enable_timing(self, classes, max_records):
         """classes: names out of TIME_CLASSES (or "all"); [] switches the timing off."""

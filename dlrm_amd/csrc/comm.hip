@@ -25,6 +25,8 @@
 #include <atomic>
 #include <mutex>
 
+#include <time.h>
+
 #include "common.h"
 
 namespace dlrm {
@@ -101,6 +103,8 @@ constexpr int kShmMaxRanks = 16;
 struct ShmHeader {
     std::atomic<int> arrived;
     std::atomic<int> generation;
+    std::atomic<int> error;        // a rank that failed inside a call says so here before it goes on to the barriers
+    std::atomic<int64_t> box_bytes;   // mailbox size of the rank that created the segment: every rank must agree
     int64_t counts[kShmMaxRanks][kShmMaxRanks];   // counts[r][p]: words rank r sends to peer p in the current call
 };
 
@@ -122,24 +126,55 @@ struct dlrm_comm {
 
 using namespace dlrm;
 
-static void shm_barrier(dlrm_comm *c) {
+// Every rank arrives, or the call fails: a peer that never comes (it died, or left the call early) must not leave
+// the others spinning for ever.  DLRM_COMM_REHEARSAL_TIMEOUT_S (default 300).
+static int shm_barrier(dlrm_comm *c) {
+    static const double limit = [] { const char *e = getenv("DLRM_COMM_REHEARSAL_TIMEOUT_S"); return e ? atof(e) : 300.0; }();
     ShmHeader *h = c->shm->hdr;
     const int gen = h->generation.load(std::memory_order_acquire);
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) == c->world - 1) {
         h->arrived.store(0, std::memory_order_relaxed);
         h->generation.store(gen + 1, std::memory_order_release);
     } else {
-        while (h->generation.load(std::memory_order_acquire) == gen) usleep(50);
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0; h->generation.load(std::memory_order_acquire) == gen; spins++) {
+            usleep(50);
+            if ((spins & 1023) == 1023) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit) {
+                    h->error.store(1, std::memory_order_release);
+                    return set_error(DLRM_ERR_HIP, "rehearsal transport: rank %d waited %.0f s for its peers", c->rank, limit);
+                }
+            }
+        }
     }
+    return DLRM_OK;
 }
 
-// this rank's n words into its mailbox (after everything queued on the stream before the call has run)
-static int shm_post(dlrm_comm *c, const float *d_send, int64_t n, hipStream_t s) {
-    DLRM_REQUIRE((size_t)n * 4 <= c->shm->box_bytes, "rehearsal transport: %lld words exceed the %zu-byte mailbox (set "
-                 "DLRM_COMM_REHEARSAL_MB)", (long long)n, c->shm->box_bytes);
-    DLRM_HIP(hipStreamSynchronize(s));
-    if (n) DLRM_HIP(hipMemcpy(c->shm->box(c->rank), d_send, (size_t)n * 4, hipMemcpyDeviceToHost));
+// what a call returns after its last barrier: its own status, or that a peer failed inside the same call
+static int shm_result(dlrm_comm *c, int rc) {
+    if (rc) return rc;
+    if (c->shm->hdr->error.load(std::memory_order_acquire))
+        return set_error(DLRM_ERR_HIP, "rehearsal transport: a peer of rank %d failed inside this call", c->rank);
     return DLRM_OK;
+}
+
+// this rank's n words into its mailbox (after everything queued on the stream before the call has run).  A failure
+// is published in the header and returned, but the caller still goes through the call's barriers: its peers are
+// waiting there.
+static int shm_post(dlrm_comm *c, const float *d_send, int64_t n, hipStream_t s) {
+    int rc = DLRM_OK;
+    if ((size_t)n * 4 > c->shm->box_bytes)
+        rc = set_error(DLRM_ERR_INVALID, "rehearsal transport: %lld words exceed the %zu-byte mailbox (set DLRM_COMM_REHEARSAL_MB)",
+                       (long long)n, c->shm->box_bytes);
+    else if (hipStreamSynchronize(s) != hipSuccess)
+        rc = set_error(DLRM_ERR_HIP, "rehearsal transport: the stream failed before the exchange");
+    else if (n && hipMemcpy(c->shm->box(c->rank), d_send, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy from the device failed");
+    if (rc) c->shm->hdr->error.store(1, std::memory_order_release);
+    return rc;
 }
 
 static_assert(DLRM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "communicator id size");
@@ -184,9 +219,19 @@ static int shm_init(const uint8_t *id, int32_t rank, int32_t world, dlrm_comm **
     t->hdr = reinterpret_cast<ShmHeader *>(p);
     dlrm_comm *h = new dlrm_comm();
     h->comm = nullptr; h->rank = rank; h->world = world; h->shm = t;
-    shm_barrier(h);                                 // everyone has mapped it
+    // the first rank to get here records its mailbox size; a rank configured otherwise would read other offsets
+    int64_t none = 0;
+    t->hdr->box_bytes.compare_exchange_strong(none, (int64_t)t->box_bytes);
+    int rc = shm_barrier(h);                        // everyone has mapped it
+    if (!rc && t->hdr->box_bytes.load() != (int64_t)t->box_bytes) {
+        t->hdr->error.store(1, std::memory_order_release);
+        rc = set_error(DLRM_ERR_INVALID, "rehearsal transport: rank %d has %zu-byte mailboxes, the segment was made with %lld "
+                       "(DLRM_COMM_REHEARSAL_MB differs between the ranks)", rank, t->box_bytes, (long long)t->hdr->box_bytes.load());
+    }
     if (rank == 0) shm_unlink(t->name);             // the mappings keep it alive; nothing is left behind
-    shm_barrier(h);
+    const int rc2 = shm_barrier(h);
+    rc = shm_result(h, rc ? rc : rc2);
+    if (rc) { munmap(t->base, t->map_bytes); delete t; delete h; return rc; }
     *out = h;
     return DLRM_OK;
 }
@@ -225,19 +270,22 @@ extern "C" int dlrm_comm_all_reduce_sum(dlrm_comm *c, float *d_buf, int64_t n, d
     if (n == 0) return DLRM_OK;
     DLRM_REQUIRE(d_buf != nullptr, "d_buf is NULL");
     if (c->shm) {
-        if (int rc = shm_post(c, d_buf, n, as_stream(stream))) return rc;
-        shm_barrier(c);
-        float *sum = new float[(size_t)n];
-        for (int64_t i = 0; i < n; i++) {
-            float a = 0.f;
-            for (int p = 0; p < c->world; p++) a += c->shm->box(p)[i];
-            sum[i] = a;
+        int rc = shm_post(c, d_buf, n, as_stream(stream));
+        if (int b = shm_barrier(c)) return b;
+        float *sum = nullptr;
+        if (!rc && !c->shm->hdr->error.load()) {
+            sum = new float[(size_t)n];
+            for (int64_t i = 0; i < n; i++) {
+                float a = 0.f;
+                for (int p = 0; p < c->world; p++) a += c->shm->box(p)[i];
+                sum[i] = a;
+            }
         }
-        shm_barrier(c);                              // everyone has read every mailbox
-        const hipError_t e = hipMemcpy(d_buf, sum, (size_t)n * 4, hipMemcpyHostToDevice);
+        if (int b = shm_barrier(c)) { delete[] sum; return b; }    // everyone has read every mailbox
+        if (sum && hipMemcpy(d_buf, sum, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy to the device failed");
         delete[] sum;
-        DLRM_HIP(e);
-        return DLRM_OK;
+        return shm_result(c, rc);
     }
     DLRM_RCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclFloat, ncclSum, c->comm, as_stream(stream)));
     return DLRM_OK;
@@ -256,9 +304,9 @@ extern "C" int dlrm_comm_all_to_all(dlrm_comm *c, const float *d_send, const int
             c->shm->hdr->counts[c->rank][p] = h_send_counts[p];
             total += h_send_counts[p];
         }
-        if (int rc = shm_post(c, d_send, total, s)) return rc;
-        shm_barrier(c);
-        int rc = DLRM_OK;
+        int rc = shm_post(c, d_send, total, s);
+        if (int b = shm_barrier(c)) return b;
+        if (!rc && c->shm->hdr->error.load()) rc = shm_result(c, DLRM_OK);
         for (int p = 0; p < c->world && !rc; p++) {
             int64_t first = 0;
             for (int q = 0; q < c->rank; q++) first += c->shm->hdr->counts[p][q];
@@ -270,8 +318,9 @@ extern "C" int dlrm_comm_all_to_all(dlrm_comm *c, const float *d_send, const int
                 rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy to the device failed");
             ro += h_recv_counts[p];
         }
-        shm_barrier(c);
-        return rc;
+        if (rc) c->shm->hdr->error.store(1, std::memory_order_release);
+        if (int b = shm_barrier(c)) return b;
+        return shm_result(c, rc);
     }
     DLRM_RCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->world; p++) {
@@ -295,19 +344,22 @@ extern "C" int dlrm_comm_reduce_scatter_sum(dlrm_comm *c, const float *d_send, f
     if (recv_count == 0) return DLRM_OK;
     DLRM_REQUIRE(d_send != nullptr && d_recv != nullptr, "NULL buffer");
     if (c->shm) {
-        if (int rc = shm_post(c, d_send, recv_count * c->world, as_stream(stream))) return rc;
-        shm_barrier(c);
-        float *sum = new float[(size_t)recv_count];
-        for (int64_t i = 0; i < recv_count; i++) {
-            float a = 0.f;
-            for (int p = 0; p < c->world; p++) a += c->shm->box(p)[(int64_t)c->rank * recv_count + i];
-            sum[i] = a;
+        int rc = shm_post(c, d_send, recv_count * c->world, as_stream(stream));
+        if (int b = shm_barrier(c)) return b;
+        float *sum = nullptr;
+        if (!rc && !c->shm->hdr->error.load()) {
+            sum = new float[(size_t)recv_count];
+            for (int64_t i = 0; i < recv_count; i++) {
+                float a = 0.f;
+                for (int p = 0; p < c->world; p++) a += c->shm->box(p)[(int64_t)c->rank * recv_count + i];
+                sum[i] = a;
+            }
         }
-        shm_barrier(c);
-        const hipError_t e = hipMemcpy(d_recv, sum, (size_t)recv_count * 4, hipMemcpyHostToDevice);
+        if (int b = shm_barrier(c)) { delete[] sum; return b; }
+        if (sum && hipMemcpy(d_recv, sum, (size_t)recv_count * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy to the device failed");
         delete[] sum;
-        DLRM_HIP(e);
-        return DLRM_OK;
+        return shm_result(c, rc);
     }
     DLRM_RCCL(g_rccl.ReduceScatter(d_send, d_recv, (size_t)recv_count, ncclFloat, ncclSum, c->comm, as_stream(stream)));
     return DLRM_OK;
@@ -319,14 +371,15 @@ extern "C" int dlrm_comm_all_gather(dlrm_comm *c, const float *d_send, float *d_
     if (send_count == 0) return DLRM_OK;
     DLRM_REQUIRE(d_send != nullptr && d_recv != nullptr, "NULL buffer");
     if (c->shm) {
-        if (int rc = shm_post(c, d_send, send_count, as_stream(stream))) return rc;
-        shm_barrier(c);
-        hipError_t e = hipSuccess;
-        for (int p = 0; p < c->world && e == hipSuccess; p++)
-            e = hipMemcpy(d_recv + (int64_t)p * send_count, c->shm->box(p), (size_t)send_count * 4, hipMemcpyHostToDevice);
-        shm_barrier(c);
-        DLRM_HIP(e);
-        return DLRM_OK;
+        int rc = shm_post(c, d_send, send_count, as_stream(stream));
+        if (int b = shm_barrier(c)) return b;
+        if (!rc && !c->shm->hdr->error.load())
+            for (int p = 0; p < c->world && !rc; p++)
+                if (hipMemcpy(d_recv + (int64_t)p * send_count, c->shm->box(p), (size_t)send_count * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    rc = set_error(DLRM_ERR_HIP, "rehearsal transport: copy to the device failed");
+        if (rc) c->shm->hdr->error.store(1, std::memory_order_release);
+        if (int b = shm_barrier(c)) return b;
+        return shm_result(c, rc);
     }
     DLRM_RCCL(g_rccl.AllGather(d_send, d_recv, (size_t)send_count, ncclFloat, c->comm, as_stream(stream)));
     return DLRM_OK;

@@ -127,10 +127,14 @@ extern "C" int dlrm_criteo_decode(const int32_t *d_records, int64_t n_samples, i
 }
 
 extern "C" int dlrm_ids_regroup(const void *d_recv, int32_t world, int64_t local_batch, int32_t n_tables,
-                                const int32_t *d_hot_offsets, int64_t offset_base, void *d_indices, void *d_offsets,
-                                int32_t idx_dtype, dlrm_stream_t stream) {
+                                const int32_t *d_hot_offsets, int64_t ids_per_sample, int64_t offset_base, void *d_indices,
+                                void *d_offsets, int32_t idx_dtype, dlrm_stream_t stream) {
     DLRM_REQUIRE(world >= 1 && local_batch >= 0 && n_tables >= 0, "bad shape");
     DLRM_REQUIRE(idx_dtype == DLRM_I32 || idx_dtype == DLRM_I64, "idx_dtype %d", idx_dtype);
+    DLRM_REQUIRE(ids_per_sample >= n_tables && (d_hot_offsets != nullptr || ids_per_sample == n_tables) && offset_base >= 0,
+                 "ids_per_sample %lld for %d tables", (long long)ids_per_sample, n_tables);
+    DLRM_REQUIRE(idx_dtype == DLRM_I64 || offset_base + ids_per_sample * local_batch * world < (1ll << 31),
+                 "offsets up to %lld do not fit 32-bit ids", (long long)(offset_base + ids_per_sample * local_batch * world));
     DLRM_REQUIRE((int64_t)world * n_tables <= 65535, "too many (rank, table) blocks");
     if (n_tables == 0 || local_batch == 0) return DLRM_OK;
     DLRM_REQUIRE(d_recv && d_indices && d_offsets, "NULL argument");

@@ -1414,12 +1414,13 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
                  "w_planes do not belong to this layer's weight matrix");
     const int64_t k32 = ceil_div(p.K, 32) * 32;
     if (!p.a_vec || (p.K % 32 != 0 && p.lda < k32)) return DLRM_OK;
-    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes through registers instead of global -> LDS directly;
-    // DLRM_F16P_WIDE=0: never the 256-column tile
+    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes through registers instead of global -> LDS directly
     static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? atoi(e) & 3 : 0; }();
-    static const bool allow_wide = [] { const char *e = getenv("DLRM_F16P_WIDE"); return !(e && e[0] == '0'); }();
-    // 128 x 256 tiles (one workgroup per compute unit) when they still give every compute unit a workgroup
-    const bool wide = allow_wide && p.N > 128 && ceil_div(p.N, 256) * ceil_div(p.M, 128) >= kTileWgs;
+    // 128 x 256 tiles -- NI = 8, one wave per SIMD with 256 accumulator registers, half the split arithmetic per MFMA --
+    // were measured slower than two 128 x 128 workgroups per compute unit on every layer of the MLPerf model at batch
+    // 65536 (1024 x 1024 forward: 543 against 486 us on one box): with one wave per SIMD nothing covers a wave's
+    // waits at the barrier and in the epilogue.  The kernel keeps the template parameter; only NI = 4 is built.
+    const bool wide = false;
     p.gx = (int)ceil_div(p.N, wide ? 256 : 128); p.gy = (int)ceil_div(p.M, 128); p.gz = 1;
     if ((int64_t)p.gx * p.gy < kTileWgs) return DLRM_OK;
     const PlaneDims d = plane_dims(wp->N, wp->K);
@@ -1433,13 +1434,8 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
     const bool tail = p.K % 32 != 0;
 #define DLRM_F16P_LAUNCH(A, B)                                                                         \
     do {                                                                                               \
-        if (wide) {                                                                                    \
-            if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 8>), grid, block, 0, s, p);     \
-            else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 8>), grid, block, 0, s, p);         \
-        } else {                                                                                       \
-            if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4>), grid, block, 0, s, p);     \
-            else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4>), grid, block, 0, s, p);         \
-        }                                                                                              \
+        if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4>), grid, block, 0, s, p);         \
+        else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4>), grid, block, 0, s, p);             \
     } while (0)
     switch (path) {
     case 0: DLRM_F16P_LAUNCH(true, true); break;

@@ -86,7 +86,7 @@ struct dlrm_model {
     float *a2a_send = nullptr, *a2a_recv = nullptr, *g_send = nullptr, *g_recv = nullptr, *rw_part = nullptr, *rw_local = nullptr;
     std::vector<int64_t> send_counts, recv_counts;
     // streams
-    hipStream_t s_emb = nullptr, s_prep = nullptr, s_wgrad = nullptr;
+    hipStream_t s_emb = nullptr, s_prep = nullptr, s_wgrad = nullptr, s_reduce = nullptr;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     // optional timing of operator classes: event pairs around the launches, on the launch stream
@@ -293,7 +293,9 @@ static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t 
         if (int rc = timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->a2a_send, (int64_t)m->Tl * D, s); }))
             return rc;
     }
-    if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->a2a_send, m->send_counts.data(), m->a2a_recv, m->recv_counts.data(), s))
+    if (int rc = timed(m, DLRM_TIME_COMM_FORWARD_EXCHANGE, s, [&] {
+            return dlrm_comm_all_to_all(m->cfg.comm, m->a2a_send, m->send_counts.data(), m->a2a_recv, m->recv_counts.data(), s);
+        }))
         return rc;
     // the block of every source rank into its columns of the feature block, one launch (not needed when the
     // interaction reads the blocks where they arrived)
@@ -315,7 +317,10 @@ static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t 
         dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
         if (int rc = timed(m, DLRM_TIME_EMBBAG_FORWARD, s, [&] { return dlrm_embbag_forward(&e, m->rw_part, (int64_t)m->Trw * D, s); }))
             return rc;
-        if (int rc = dlrm_comm_reduce_scatter_sum(m->cfg.comm, m->rw_part, m->rw_local, B * m->Trw * D, s)) return rc;
+        if (int rc = timed(m, DLRM_TIME_COMM_FORWARD_EXCHANGE, s, [&] {
+                return dlrm_comm_reduce_scatter_sum(m->cfg.comm, m->rw_part, m->rw_local, B * m->Trw * D, s);
+            }))
+            return rc;
         if (!m->views)
             if (int rc = dlrm_copy_2d(m->feat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, m->rw_local, (int64_t)m->Trw * D, B,
                                       (int64_t)m->Trw * D, s))
@@ -363,7 +368,10 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
         }
         if (int rc = dlrm_copy_2d_many(items.data(), (int32_t)items.size(), s)) return rc;
     }
-    if (int rc = dlrm_comm_all_to_all(m->cfg.comm, m->g_send, m->recv_counts.data(), m->g_recv, m->send_counts.data(), s)) return rc;
+    if (int rc = timed(m, DLRM_TIME_COMM_BACKWARD_EXCHANGE, s, [&] {
+            return dlrm_comm_all_to_all(m->cfg.comm, m->g_send, m->recv_counts.data(), m->g_recv, m->send_counts.data(), s);
+        }))
+        return rc;
     if (m->Tl)
         if (int rc = sparse_update(m, false, idx, off, n_idx, m->g_recv, (int64_t)m->Tl * D, s)) return rc;
     if (m->Trw) {
@@ -371,7 +379,10 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
             if (int rc = dlrm_copy_2d(m->rw_local, (int64_t)m->Trw * D, m->dfeat + m->emb_col0 + (int64_t)m->n_tw * D, m->feat_ld, B,
                                       (int64_t)m->Trw * D, s))
                 return rc;
-        if (int rc = dlrm_comm_all_gather(m->cfg.comm, m->rw_local, m->rw_part, B * m->Trw * D, s)) return rc;
+        if (int rc = timed(m, DLRM_TIME_COMM_BACKWARD_EXCHANGE, s, [&] {
+                return dlrm_comm_all_gather(m->cfg.comm, m->rw_local, m->rw_part, B * m->Trw * D, s);
+            }))
+            return rc;
         if (int rc = sparse_update(m, true, idx, off, n_idx, m->rw_part, (int64_t)m->Trw * D, s)) return rc;
     }
     return DLRM_OK;
@@ -468,6 +479,7 @@ extern "C" int dlrm_model_destroy(dlrm_model *m) {
     if (m->s_emb) (void)hipStreamDestroy(m->s_emb);
     if (m->s_prep) (void)hipStreamDestroy(m->s_prep);
     if (m->s_wgrad) (void)hipStreamDestroy(m->s_wgrad);
+    if (m->s_reduce) (void)hipStreamDestroy(m->s_reduce);
     delete m;
     return DLRM_OK;
 }
@@ -546,6 +558,8 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
         if (hipStreamCreateWithFlags(&m->s_prep, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
     if (c->wgrad_stream < 0 ? c->local_batch <= 32768 : c->wgrad_stream != 0)
         if (hipStreamCreateWithFlags(&m->s_wgrad, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
+    if (sharded && c->comm_dense != nullptr)      // the dense gradients' all-reduce beside the rest of the backward pass
+        if (hipStreamCreateWithFlags(&m->s_reduce, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
     m->events.resize(64);
     for (auto &e : m->events)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "event"));
@@ -916,14 +930,34 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
         if (int rc = linear_dgrad(m, m->topl[0], 0, nb, dz0, dz0_ld, m->dfeat, m->feat_ld, m->feat, m->feat_ld, main)) return rc;
         if (int rc = linear_dgrad(m, m->topl[0], nb, m->top_in - nb, dz0, dz0_ld, m->dfeat + nb, m->feat_ld, nullptr, 0, main)) return rc;
     }
+    // with a communicator of its own the all-reduce of the top MLP's gradients (most of the dense parameters) starts
+    // here, on its own stream, beside the exchange, the sparse update and the bottom MLP's backward pass
+    const bool early_reduce = m->sharded && c.comm_dense != nullptr && m->s_reduce != nullptr;
+    const int64_t top_off = m->topl.front().w_off;
+    if (early_reduce) {
+        if (int rc = wait_for(m, m->s_reduce, m->s_wgrad ? m->s_wgrad : main)) return rc;    // the top stack's weight gradients are there
+        if (int rc = timed(m, DLRM_TIME_COMM_ALL_REDUCE, m->s_reduce, [&] {
+                return dlrm_comm_all_reduce_sum(c.comm_dense, m->grads + top_off, m->n_params - top_off, m->s_reduce);
+            }))
+            return rc;
+    }
     // sparse rows (exchange + fused update) on the embedding stream beside the bottom MLP's backward
     if (int rc = wait_for(m, emb, main)) return rc;     // dfeat is complete
     if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, emb)) return rc;
     if (int rc = stack_backward(m, m->bot, m->x_dense, m->x_ld, m->bot_acts, m->dfeat, m->feat_ld, m->bot_dz, nullptr, 0, main)) return rc;
     if (m->s_wgrad)
         if (int rc = wait_for(m, main, m->s_wgrad)) return rc;   // every dense gradient is there
-    if (m->sharded)
-        if (int rc = dlrm_comm_all_reduce_sum(c.comm, m->grads, m->n_params, main)) return rc;
+    if (early_reduce) {
+        if (int rc = wait_for(m, m->s_reduce, main)) return rc;
+        if (int rc = timed(m, DLRM_TIME_COMM_ALL_REDUCE, m->s_reduce,
+                           [&] { return dlrm_comm_all_reduce_sum(c.comm_dense, m->grads, top_off, m->s_reduce); }))
+            return rc;
+        if (int rc = wait_for(m, main, m->s_reduce)) return rc;
+    } else if (m->sharded) {
+        dlrm_comm *cd = c.comm_dense ? c.comm_dense : c.comm;
+        if (int rc = timed(m, DLRM_TIME_COMM_ALL_REDUCE, main, [&] { return dlrm_comm_all_reduce_sum(cd, m->grads, m->n_params, main); }))
+            return rc;
+    }
     if (int rc = wait_for(m, main, emb)) return rc;      // rows are updated before anyone reuses dfeat
     if (int rc = wait_for(m, main, side)) return rc;     // the loss value is there before anyone overwrites the predictions
     return dlrm_sgd_step(m->params, m->grads, m->n_params, c.lr, main);

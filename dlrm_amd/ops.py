@@ -486,9 +486,10 @@ def ids_regroup(recv, world, local_batch, n_tables, hot_offsets=None, offset_bas
         indices = torch.empty(recv.numel(), dtype=recv.dtype, device=recv.device)
     if offsets is None:
         offsets = torch.empty(n_tables * Bg + 1, dtype=recv.dtype, device=recv.device)
+    per_sample = recv.numel() // Bg if Bg else n_tables      # the sum of these tables' hotness
     check(_capi.lib().dlrm_ids_regroup(_ptr(recv), C.c_int32(world), C.c_int64(local_batch), C.c_int32(n_tables),
-                                       _ptr(hot_offsets), C.c_int64(offset_base), _ptr(indices), _ptr(offsets),
-                                       _idx_dtype(recv), _stream()))
+                                       _ptr(hot_offsets), C.c_int64(per_sample), C.c_int64(offset_base), _ptr(indices),
+                                       _ptr(offsets), _idx_dtype(recv), _stream()))
     return indices, offsets
 
 

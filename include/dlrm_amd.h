@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1014
+#define DLRM_ABI_VERSION 1015
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -489,11 +489,14 @@ int dlrm_criteo_decode(const int32_t *d_records, int64_t n_samples, int32_t n_de
  * d_indices receives them table-major over the global batch (sample r*local_batch + b), d_offsets the CSR
  * offsets (n_tables*world*local_batch + 1), each raised by offset_base (d_indices may be the tail of a longer
  * index array whose head holds other tables).  d_hot_offsets: device int32[n_tables+1] prefix sums of these
- * tables' hotness, NULL = one id per bag.
+ * tables' hotness IN THE ORDER THE TABLES HAVE INSIDE d_recv (this rank's local-table order, not the record order
+ * dlrm_criteo_decode indexes its array by), NULL = one id per bag; ids_per_sample = their total (n_tables when
+ * NULL).  With 32-bit ids the largest offset, offset_base + ids_per_sample * world * local_batch, must stay below
+ * 2^31 (refused otherwise: it would wrap into negative CSR offsets).
  */
 int dlrm_ids_regroup(const void *d_recv, int32_t world, int64_t local_batch, int32_t n_tables,
-                     const int32_t *d_hot_offsets, int64_t offset_base, void *d_indices, void *d_offsets,
-                     int32_t idx_dtype, dlrm_stream_t stream);
+                     const int32_t *d_hot_offsets, int64_t ids_per_sample, int64_t offset_base, void *d_indices,
+                     void *d_offsets, int32_t idx_dtype, dlrm_stream_t stream);
 
 /* ---- recorded step ------------------------------------------------------------------------
  *
@@ -804,6 +807,11 @@ typedef struct dlrm_model_config {
                                  /* n_indices, stream) and replays the graph afterwards (the 8 most recent sets are */
                                  /* kept): for hosts that cycle resident buffers.  The caller's stream must not be the */
                                  /* NULL stream.  Sharded models and steps with operator timing launch directly. */
+    dlrm_comm *comm_dense;       /* NULL, or a SECOND communicator over the same ranks for the all-reduce of the dense */
+                                 /* gradients: RCCL serialises the operations of one communicator, so only with its own */
+                                 /* one does that all-reduce run beside the backward exchange of the embedding side.  The */
+                                 /* top MLP's gradients are then reduced as soon as that stack's backward pass is done */
+                                 /* (beside the interaction's and the bottom MLP's), the bottom MLP's at the end */
 } dlrm_model_config;
 
 typedef struct dlrm_model_info_t {
@@ -863,7 +871,10 @@ enum {
     DLRM_TIME_LINEAR_FORWARD = 0, DLRM_TIME_LINEAR_BACKWARD_DATA, DLRM_TIME_LINEAR_BACKWARD_WEIGHT,
     DLRM_TIME_LINEAR_FORWARD_SKINNY, DLRM_TIME_LINEAR_BACKWARD_DATA_SKINNY, DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY,
     DLRM_TIME_EMBBAG_FORWARD, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, DLRM_TIME_EMBBAG_BACKWARD_UPDATE,
-    DLRM_TIME_INTERACT_DOT_FORWARD, DLRM_TIME_INTERACT_DOT_BACKWARD, DLRM_TIME_NUM_CLASSES
+    DLRM_TIME_INTERACT_DOT_FORWARD, DLRM_TIME_INTERACT_DOT_BACKWARD,
+    /* the collectives of a sharded step (time on their stream, waiting for the slowest peer included) */
+    DLRM_TIME_COMM_FORWARD_EXCHANGE, DLRM_TIME_COMM_BACKWARD_EXCHANGE, DLRM_TIME_COMM_ALL_REDUCE,
+    DLRM_TIME_NUM_CLASSES
 };
 int dlrm_model_enable_timing(dlrm_model *m, uint32_t class_mask, int32_t max_records);
 int dlrm_model_collect_timing(dlrm_model *m, double *h_ms_sum, int64_t *h_launches);

@@ -46,14 +46,16 @@ def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged, gemm):
         pytest.skip("the evaluation mode does not touch the sparse path: covered at the other corners")
     cfg = small_cfgs()[name]
     B, T = 37, cfg.num_tables
-    cm, owner = None, None
+    cm, cm2, owner = None, None, None
     if mode != "single":
         cm = comm.Comm(comm.unique_id(), 0, 1)
+        if ragged or gemm == "f16x2":  # ... with a second communicator for the dense gradients' all-reduce, which then
+            cm2 = comm.Comm(comm.unique_id(), 0, 1)     # starts behind the top MLP's backward pass on a stream of its own
         if mode == "exchange-rw":      # the two largest tables are split by rows (one range: the only rank's)
             big = sorted(range(T), key=lambda t: -cfg.table_rows[t])[:2]
             owner = [-1 if t in big else 0 for t in range(T)]
     m = CModel(cfg, B, comm=cm, table_owner=owner, seed=3, force_exchange=mode != "single", idx_dtype=torch.int64,
-               gemm_mode=_capi.GEMM_F16X2 if gemm == "f16x2" else 0)
+               gemm_mode=_capi.GEMM_F16X2 if gemm == "f16x2" else 0, comm_dense=cm2)
     m.init_dense(7)
     Ws, bs = m.get_dense()
     if name == "rmc1_like":            # positive biases keep the all-ReLU reference model alive
@@ -92,6 +94,8 @@ def test_c_hosted_train_step_matches_oracle(oracle, name, mode, ragged, gemm):
                                     emb_opt_state=None if state is None else state.copy())
     assert rel_err(pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
     m.close()
+    if cm2 is not None:
+        cm2.close()
     if cm is not None:
         cm.close()
 
@@ -157,7 +161,7 @@ def test_c_hosted_one_id_per_bag_reads_rows_in_the_interaction(oracle, shape):
     b.close()
 
 
-def _rank_worker(rank, world, comm_id, name, rw, ret):
+def _rank_worker(rank, world, comm_id, comm_id2, name, rw, ret):
     """One rank of a C-hosted sharded run on GPU 0 (rehearsal transport of dlrm_comm: RCCL refuses ranks that share
     a device): its slice of the global batch, the ids of its tables for the whole batch, compared with the oracle's
     single-process step on the global batch."""
@@ -170,12 +174,13 @@ def _rank_worker(rank, world, comm_id, name, rw, ret):
         Bl, T = 12, cfg.num_tables
         Bg = Bl * world
         cm = comm.Comm(comm_id, rank, world)
+        cm2 = comm.Comm(comm_id2, rank, world) if comm_id2 is not None else None
         owner = None
         if rw:                       # the two largest tables are split by rows over all ranks, the rest placed whole
             big = sorted(range(T), key=lambda t: -cfg.table_rows[t])[:2]
             rest = [t for t in range(T) if t not in big]
             owner = [-1 if t in big else rest.index(t) % world for t in range(T)]
-        m = CModel(cfg, Bl, rank=rank, world=world, comm=cm, table_owner=owner, seed=3, idx_dtype=torch.int64)
+        m = CModel(cfg, Bl, rank=rank, world=world, comm=cm, table_owner=owner, seed=3, idx_dtype=torch.int64, comm_dense=cm2)
         m.init_dense(7)
         Ws, bs = m.get_dense()
         if name == "rmc1_like":
@@ -212,6 +217,8 @@ def _rank_worker(rank, world, comm_id, name, rw, ret):
                 if rel_err(a, r) > 1e-5:
                     bad.append("dense parameter %d step %d" % (n, step))
         m.close()
+        if cm2 is not None:
+            cm2.close()
         cm.close()
         ret[rank] = "; ".join(bad) if bad else True
     except Exception as e:       # the parent sees what went wrong instead of a bare exit code
@@ -226,13 +233,15 @@ def test_c_hosted_sharded_step_several_ranks_one_gpu(name, rw, world):
     """The C-hosted sharded step with 2 and 3 ranks (whole tables per rank: all-to-all of pooled vectors and their
     gradients with per-peer counts; row-wise tables: reduce-scatter / all-gather; all-reduce of the dense
     gradients) against the single-process oracle.  The ranks share GPU 0 and exchange through dlrm_comm's rehearsal
-    transport, which carries out the same calls in shared host memory."""
+    transport, which carries out the same calls in shared host memory.  The row-wise cases give the dense gradients
+    a communicator of their own (dlrm_model_config.comm_dense: two all-reduces, the top MLP's started early)."""
     import torch.multiprocessing as mp
     from dlrm_amd import comm
     comm_id = comm.unique_id_rehearsal()
+    comm_id2 = comm.unique_id_rehearsal() if rw else None
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_rank_worker, args=(world, comm_id, name, rw, ret), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, comm_id, comm_id2, name, rw, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
 
 

@@ -112,3 +112,18 @@ def test_ids_regroup_matches_restatement(idx_t, world, B, hot):
         i_ref, o_ref = criteo_oracle.regroup(recv, world, B, hot, base)
         assert np.array_equal(idx.cpu().numpy().astype(np.int64), i_ref)
         assert np.array_equal(off.cpu().numpy().astype(np.int64), o_ref)
+
+
+def test_ids_regroup_refuses_offsets_beyond_32_bits():
+    """32-bit ids: an offset base that would push the CSR offsets past 2^31 is refused on the host (they would wrap into
+    negative offsets that the EmbeddingBag kernels then read); the same call with 64-bit ids goes through."""
+    from dlrm_amd import _capi, ops
+    world, B, hot = 2, 16, [3, 1]
+    recv = torch.zeros(world * B * sum(hot), dtype=torch.int32, device="cuda")
+    hot_off = torch.tensor([0, 3, 4], dtype=torch.int32, device="cuda")
+    base = 2**31 - 100
+    with pytest.raises(_capi.DlrmError, match="32-bit"):
+        ops.ids_regroup(recv, world, B, len(hot), hot_off, base)
+    idx, off = ops.ids_regroup(recv.to(torch.int64), world, B, len(hot), hot_off, base)
+    torch.cuda.synchronize()
+    assert int(off[-1].item()) == base + world * B * sum(hot)
