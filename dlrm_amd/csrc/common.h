@@ -105,6 +105,16 @@ struct AbsmaxItem {
 };
 int absmax_many(const AbsmaxItem *items, int n, hipStream_t s);
 
+// Stable sort of (key, value) pairs by the low `bits` bits of the key (pair_sort.hip: least-significant-digit radix sort,
+// digits of up to 10 bits).  The pairs start in (keys_a, vals_a) and end there when pair_sort_passes(bits) is even, in
+// (keys_b, vals_b) when it is odd; both pairs of buffers are overwritten.  tmp: pair_sort_tmp_bytes(n) bytes.
+int pair_sort_passes(int bits);
+size_t pair_sort_tmp_bytes(int64_t n);
+int pair_sort(uint32_t *keys_a, uint32_t *keys_b, int32_t *vals_a, int32_t *vals_b, int64_t n, int bits, void *tmp,
+              size_t tmp_bytes, hipStream_t s);
+int pair_sort(uint64_t *keys_a, uint64_t *keys_b, int32_t *vals_a, int32_t *vals_b, int64_t n, int bits, void *tmp,
+              size_t tmp_bytes, hipStream_t s);
+
 // dlrm_interact_dot_forward_gather / dlrm_interact_dot_backward with one more output (interact.hip): the largest
 // magnitude of the interaction's output / of feature 0's gradient, folded into a slot like the GEMM epilogues do
 int interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,

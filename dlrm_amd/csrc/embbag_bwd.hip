@@ -2,10 +2,11 @@
 //
 //  1. expand : every occurrence p of a row in the batch becomes a pair
 //              (key = global row, value = bag).
-//  2. sort   : stable LSD radix sort of the pairs by key (rocPRIM device
-//              primitive, only as many key bits as total_rows needs).  Stability
-//              keeps the occurrences of one row in position order, so the
-//              reduction order -- and the result -- is reproducible.
+//  2. sort   : stable LSD radix sort of the pairs by key (pair_sort.hip, only as
+//              many key bits as total_rows needs; DLRM_SORT=rocprim in the
+//              environment: rocPRIM's device primitive instead, for comparison).
+//              Stability keeps the occurrences of one row in position order, so
+//              the reduction order -- and the result -- is reproducible.
 //  3. update : segmented reduction over the sorted occurrences fused with the optimizer step
 //              (sparse_update_kernel).  A workgroup owns one or two stretches of kSegLen sorted
 //              positions, each G-lane group a few consecutive positions of it, fetched kChunk gradient
@@ -18,6 +19,8 @@
 //
 // HBM-bound: algorithmic bytes per call = n_idx*dim*4 (gradient rows) +
 // 2*U*dim*row_bytes (read-modify-write of U unique rows) + n_idx*idx_bytes.
+#include <stdlib.h>
+
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -72,6 +75,8 @@ static int ws_layout(int64_t n, int bits, int dim, void *base, WsLayout<KEY> *L)
     L->keys_out = reinterpret_cast<KEY *>(p + o); o += align_up(sizeof(KEY) * (size_t)n);
     L->vals_in = reinterpret_cast<int32_t *>(p + o); o += align_up(sizeof(int32_t) * (size_t)n);
     L->vals_out = reinterpret_cast<int32_t *>(p + o); o += align_up(sizeof(int32_t) * (size_t)n);
+    const size_t own = pair_sort_tmp_bytes(n);
+    tmp = tmp > own ? tmp : own;                      // (room for either sort)
     L->sort_tmp = p + o; o += align_up(tmp);
     L->sort_tmp_bytes = tmp;
     L->partial = reinterpret_cast<float *>(p + o);
@@ -662,12 +667,22 @@ static int run_backward(const dlrm_embbag *e, BwdParams &p, void *ws, size_t ws_
         int lpb = 1;
         while (lpb < 64 && lpb * 2 <= avg_len) lpb <<= 1;
         const int64_t blocks = ceil_div(p.n_bags * lpb, kBwdThreads);
+        static const bool use_rocprim = [] { const char *v = getenv("DLRM_SORT"); return v && strcmp(v, "rocprim") == 0; }();
+        // the sorted pairs must end in (keys_out, vals_out): the library's own sort alternates between the two pairs of
+        // buffers once per pass, so with an even number of passes the pairs start out in the "out" buffers
+        const bool start_in_out = !use_rocprim && pair_sort_passes(bits) % 2 == 0;
+        KEY *k0 = start_in_out ? L.keys_out : L.keys_in, *k1 = start_in_out ? L.keys_in : L.keys_out;
+        int32_t *v0 = start_in_out ? L.vals_out : L.vals_in, *v1 = start_in_out ? L.vals_in : L.vals_out;
         hipLaunchKernelGGL((expand_pairs_kernel<IDX, KEY>), dim3((unsigned)blocks + kTailBlocks), dim3(kBwdThreads), 0, s,
-                           p, lpb, (unsigned)blocks, L.keys_in, L.vals_in);
+                           p, lpb, (unsigned)blocks, k0, v0);
         DLRM_LAUNCH_CHECK();
-        size_t tmp = L.sort_tmp_bytes;
-        DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
-                                           (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
+        if (use_rocprim) {
+            size_t tmp = L.sort_tmp_bytes;
+            DLRM_HIP(rocprim::radix_sort_pairs(L.sort_tmp, tmp, L.keys_in, L.keys_out, L.vals_in, L.vals_out,
+                                               (size_t)e->n_indices, 0u, (unsigned)bits, s, false));
+        } else {
+            if (int rc = pair_sort(k0, k1, v0, v1, e->n_indices, bits, L.sort_tmp, L.sort_tmp_bytes, s)) return rc;
+        }
     }
     if (!(phases & 2)) return DLRM_OK;
     if (e->row_dtype == DLRM_BF16)

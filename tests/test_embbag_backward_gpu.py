@@ -102,3 +102,43 @@ def test_backward_reports_bad_index_and_updates_the_rest(oracle):
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
     assert rel_err(dw.cpu().numpy(), w_ref) <= 1e-5
+
+
+_SORT_CASE = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from dlrm_amd import ops
+g = torch.Generator(device="cuda").manual_seed(11)
+rows = [3, 70000, 1, 5000000, 129, 2, 40000, 900001]           # 1 .. 23 key bits per table, 23 bits in all: three passes
+B, D, L = 6001, 32, 3
+tro = torch.tensor([0] + torch.tensor(rows).cumsum(0).tolist(), dtype=torch.int64, device="cuda")
+w = torch.randn(int(tro[-1]), D, device="cuda", generator=g)
+idx = torch.cat([torch.randint(0, r, (B * L,), device="cuda", generator=g) for r in rows]).to(torch.int32)
+idx[5::97] = -1                                                  # ids the update must skip
+off = torch.arange(0, len(rows) * B * L + 1, L, device="cuda", dtype=torch.int32)
+grad = torch.randn(B, len(rows) * D, device="cuda", generator=g)
+for last_wins in (False, True):
+    ops.embbag_backward_update(w, idx, off, B, grad, len(rows), tro, 0, True, lr=0.1,
+                               dup_mode=1 if last_wins else 0)
+torch.cuda.synchronize()
+torch.save(w.cpu(), sys.argv[1])
+"""
+
+
+def test_own_sort_gives_the_rows_the_rocprim_sort_gives(tmp_path):
+    """The library's own pair sort (pair_sort.hip) against rocPRIM's radix sort (DLRM_SORT=rocprim, read once per
+    process: two child processes): the same seeded update -- eight tables of 1 to 23 key bits, three ids per bag,
+    out-of-range ids among them, accumulate then last-wins (which depends on the order INSIDE a run of equal keys,
+    i.e. on the sort's stability) -- must leave bit-identical tables."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "case.py"
+    script.write_text(_SORT_CASE % {"root": root})
+    outs = []
+    for name, env in (("own", {}), ("rocprim", {"DLRM_SORT": "rocprim"})):
+        out = tmp_path / (name + ".pt")
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(os.environ, **env), timeout=280)
+        outs.append(torch.load(out, weights_only=True))
+    assert torch.equal(outs[0], outs[1])
