@@ -72,8 +72,8 @@ struct GemmParams {
                           // (the bias gradient of the weight-gradient product), or NULL
     const float *a_max, *b_max;   // f16x2 evaluation: device scalars holding max |A|, max |B| (float32 bit patterns)
     float *c_max;         // or NULL: max |C| over everything this launch stores is folded in with atomicMax
-    const unsigned char *bp_h, *bp_l;   // gemm_f16p_kernel: the f16 planes of B [N rounded up to 128][bp_ld bytes], zero padded
-    int64_t bp_ld;
+    const unsigned char *bp_h, *bp_l;   // gemm_f16p_kernel: the f16 planes of B, [reduction step][N rounded up to 256][32] f16,
+    int64_t bp_ld;                      // zero padded; bp_ld = bytes per reduction step
 };
 
 // Global -> register staging of one operand tile (4 x 16 bytes per thread).
@@ -892,13 +892,23 @@ __device__ inline void f16p_interleave() {
 // NI: 32-column MFMA tiles per wave (4: 128 x 128 outputs per workgroup, two workgroups per compute unit; 8: 128 x 256,
 // 256 accumulator registers per wave, one workgroup per compute unit -- one wave per SIMD with the whole register file:
 // half the split arithmetic and A traffic per MFMA)
-template <bool TAIL, bool ADMA, bool BDMA, int NI>
+// ABL (diagnostic builds only, -DDLRM_F16P_ABLATE; results are wrong, timings tell what a step waits for): bit 0 = no
+// global loads inside the loop, bit 1 = no split arithmetic (raw bits as pieces), bit 2 = no barrier per step,
+// bit 4 = one column tile's B fragments reused for all (a quarter of the LDS reads), bit 5 / bit 6 = no loads of A / of B
+// inside the loop
+// AST: stages of raw A rows (ADMA only).  2: the rows of step t+2 are requested during step t and split during step
+// t+1 -- one step to arrive; 3: those of step t+3, two steps to arrive (80 KB of LDS per workgroup, still two per
+// compute unit).  Measured equal (the kernel does not wait for A; with all of its parts it runs at the chip's power
+// limit, 1.7 GHz in back-to-back launches: every part's cost shows up in the clock); only 2 is built outside the
+// diagnostic build.
+template <bool TAIL, bool ADMA, bool BDMA, int NI, int ABL = 0, int AST = 2>
 __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kernel(GemmParams p) {
     constexpr int kPStage = 4096 * NI;          // bytes per B stage: h plane, l plane, 32 NI rows of 64 bytes each
     // LDS: two stages of B planes (16 KB each, shared by the four waves), then two stages of raw float32 A rows
     // (16 KB each: 4 KB per wave, read only by the wave that fetched them)
     constexpr int kAStage = 4 * 32 * 128, kAOff = 2 * kPStage;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage + 2 * kAStage];
+    static_assert(AST == 2 || (AST == 3 && ADMA), "three A stages exist for the direct-to-LDS path only");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage + AST * kAStage];
     static_assert(2 * kPStage + 2 * kAStage >= 4 * 32 * (64 + 4) * 4, "the epilogue parks 32 x 64 per wave at a time");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void lds_void;
@@ -937,10 +947,10 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
     // instruction).  Waves 0, 1 bring the lower / upper half of the h plane's rows, waves 2, 3 of the l plane's, NI
     // instructions each; the swizzle is applied on the global side: the lane that fills position pp of row n fetches
     // the row's chunk pp ^ ((n >> 2) & 3).
-    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 16 * NI * (uwave & 1)) * p.bp_ld;
-    const unsigned b_off = (unsigned)((lane >> 2) * (int)p.bp_ld + 16 * (BDMA ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)));
+    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 16 * NI * (uwave & 1)) * 64;
+    const unsigned b_off = (unsigned)((lane >> 2) * 64 + 16 * (BDMA ? ((lane & 3) ^ ((lane >> 4) & 3)) : (lane & 3)));
     const int b_wr = (lane >> 2) * 64 + 16 * ((lane & 3) ^ ((lane >> 4) & 3));        // + 1024 j (register path)
-    const unsigned b_off16 = (unsigned)(16 * (int)p.bp_ld);
+    const unsigned b_off16 = 1024u;                     // (16 rows of a step are 1 KB of the plane)
     const int b_lds = (uwave >> 1) * (2048 * NI) + (uwave & 1) * (1024 * NI);       // this wave's share of a B stage
     const int rd0 = bp_lds_off(l31, 2 * half), rd1 = bp_lds_off(l31, 2 * half + 1);   // slice 0 / 1, + 2048 per column tile
 
@@ -950,18 +960,18 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
 #pragma unroll
         for (int r = 0; r < 16; r++) { hi[ni][r] = 0.f; lo[ni][r] = 0.f; }
 
-    auto dma_a = [&](int t, int stage) {
+    auto dma_a = [&](int t, int stage_off) {
         const int tc = t < steps ? t : steps - 1;     // (surplus requests re-read the last step)
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_origin + 32 * tc), 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + a_lds + stage * kAStage + 1024 * j), 16, (int)a_off[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + a_lds + stage_off + 1024 * j), 16, (int)a_off[j], 0, 0, 0);
     };
     auto dma_b = [&](int t, int stage) {
         const int tc = t < steps ? t : steps - 1;
         const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + tc * p.bp_ld), 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NI; j++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + b_lds + stage * kPStage + 1024 * j), 16, (int)(b_off + j * b_off16), 0, 0, 0);
@@ -974,15 +984,15 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
 #pragma unroll
         for (int j = 0; j < 4; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)a_off[j], 0, 0);
     };
-    auto store_a = [&](int stage, const u32x4 (&r)[4]) {
+    auto store_a = [&](int stage_off, const u32x4 (&r)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            *reinterpret_cast<u32x4 *>(smem + a_lds + stage * kAStage + 1024 * j + (a_wr ^ (64 * (j & 1)))) = r[j];
+            *reinterpret_cast<u32x4 *>(smem + a_lds + stage_off + 1024 * j + (a_wr ^ (64 * (j & 1)))) = r[j];
     };
     auto load_b = [&](int t, u32x4 (&r)[NI]) {
         const int tc = t < steps ? t : steps - 1;
         const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + 64 * tc), 0, 0xffffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + tc * p.bp_ld), 0, 0xffffffff, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NI; j++) r[j] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(b_off + j * b_off16), 0, 0);
     };
@@ -991,8 +1001,8 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
         for (int j = 0; j < NI; j++) *reinterpret_cast<u32x4 *>(smem + b_lds + stage * kPStage + 1024 * j + b_wr) = r[j];
     };
     // this lane's 16 float32 of a step out of the wave's A image
-    auto read_a = [&](int stage, f32x4 (&r)[4]) {
-        const unsigned char *base = smem + a_lds + stage * kAStage + a_rd;
+    auto read_a = [&](int stage_off, f32x4 (&r)[4]) {
+        const unsigned char *base = smem + a_lds + stage_off + a_rd;
 #pragma unroll
         for (int q = 0; q < 4; q++) r[q] = *reinterpret_cast<const f32x4 *>(base + 16 * ((4 * half + q) ^ a_sw));
     };
@@ -1004,8 +1014,9 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
             const int rd = s ? rd1 : rd0;
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
-                const f16x8 bh = *reinterpret_cast<const f16x8 *>(stage + rd + ni * 2048);
-                const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 2048 * NI + rd + ni * 2048);
+                const int nb = (ABL & 16) ? 0 : ni * 2048;
+                const f16x8 bh = *reinterpret_cast<const f16x8 *>(stage + rd + nb);
+                const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 2048 * NI + rd + nb);
                 f32x16 c = lo[ni];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
@@ -1020,38 +1031,52 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
     // step t (parity par): MFMAs on (B stage par, f_c); meanwhile the raw A of step t+1 (A stage par^1) is read and
     // split into f_n, the B planes of step t+1 travel to B stage par^1, the A rows of step t+2 to A stage par (whose
     // rows were split during the previous step)
+    // (three A stages: the stage step t's requests fill and the one its split reads rotate -- scalar offsets)
+    int a_fill = 0, a_split = kAStage;
     auto step = [&](int t, int par, bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
-        if constexpr (BDMA) dma_b(t + 1, par ^ 1);        // (every wave has passed the barrier behind its last read of that stage)
+        constexpr bool kLoadA = !(ABL & 1) && !(ABL & 32), kLoadB = !(ABL & 1) && !(ABL & 64);
+        if constexpr (!kLoadB) {}
+        else if constexpr (BDMA) dma_b(t + 1, par ^ 1);   // (every wave has passed the barrier behind its last read of that stage)
         else load_b(t + 1, bst);
-        if constexpr (ADMA) dma_a(t + 2, par);
+        if constexpr (!kLoadA) {}
+        else if constexpr (ADMA) dma_a(t + AST, AST == 2 ? par * kAStage : a_fill);
         else load_a(t + 2, ast);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ADMA) {
-            // the A rows of step t+1 have landed (requests issued since then may be in flight: NI + 4 here, fewer if B
-            // goes through registers -- those are counted by the compiler's own waits)
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (NI + 4));          // vmcnt(NI + 4)
+        if constexpr (ADMA && kLoadA) {
+            // the A rows of step t+1 have landed (requests issued since then may be in flight: NI + 4 of this step, with
+            // three stages also the 4 A requests of the step before; fewer if B goes through registers -- those are
+            // counted by the compiler's own waits)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | ((kLoadB ? NI : 0) + 4 * (AST - 1)));
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 raw[4];
-        read_a(par ^ 1, raw);
-        f16p_split<TAIL>(raw, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
+        read_a(AST == 2 ? (par ^ 1) * kAStage : a_split, raw);
+        if constexpr (AST == 3) {
+            a_fill = a_fill == 2 * kAStage ? 0 : a_fill + kAStage;
+            a_split = a_split == 2 * kAStage ? 0 : a_split + kAStage;
+        }
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) f_n[q >> 1][q & 1] = __builtin_bit_cast(bf16x8, raw[q]);
+        } else f16p_split<TAIL>(raw, scale_a, p.K - 32 * (t + 1) - 16 * half, f_n);    // (step t + 1's elements)
         mfma_step(smem + par * kPStage, f_c);
         if constexpr (!BDMA) store_b(par ^ 1, bst);
-        if constexpr (!ADMA) store_a(par, ast);
+        if constexpr (!ADMA) store_a(par * kAStage, ast);
         f16p_interleave<0, NI, (BDMA ? 0 : NI) + (ADMA ? 0 : 4)>();
         __builtin_amdgcn_sched_barrier(0);
         // this wave's pieces of the next B stage have landed (A requests issued behind them may stay in flight)
-        if constexpr (BDMA) __builtin_amdgcn_s_waitcnt(0x0F74);
-        __syncthreads();
+        if constexpr (BDMA && kLoadB) __builtin_amdgcn_s_waitcnt(0x0F70 | (kLoadA ? 4 : 0));
+        if constexpr (!(ABL & 4)) __syncthreads();
     };
     if constexpr (ADMA) dma_a(0, 0); else load_a(0, ast);
     if constexpr (BDMA) dma_b(0, 0); else load_b(0, bst);
     if constexpr (!ADMA) store_a(0, ast);
     if constexpr (!BDMA) store_b(0, bst);
-    if constexpr (ADMA) dma_a(1, 1);
-    else { load_a(1, ast); store_a(1, ast); }
+    if constexpr (ADMA) dma_a(1, kAStage);
+    else { load_a(1, ast); store_a(kAStage, ast); }
+    if constexpr (AST == 3) dma_a(2, 2 * kAStage);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ADMA || BDMA) __builtin_amdgcn_s_waitcnt(ADMA ? 0x0F74 : 0x0F70);
+    if constexpr (ADMA || BDMA) __builtin_amdgcn_s_waitcnt(ADMA ? (0x0F70 | (4 * (AST - 1))) : 0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     {
         f32x4 raw[4];
@@ -1085,10 +1110,12 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
 }
 
 // ---- the planes gemm_f16p_kernel reads: for a weight matrix W [N,K], its f16 pieces (times the scale of max |W|) as
-// [N rounded up to 256][K rounded up to 32] (forward: reduction over K) and, transposed, [K rounded up to 256][N
-// rounded up to 32] (backward-data: reduction over N), zero in the padding.  Layout of the buffer: forward h, forward
-// l, transposed h, transposed l.
-struct PlaneDims { int64_t f_rows, f_ld, t_rows, t_ld; };     // rows and leading dimension (f16 elements) of the two images
+// [K rounded up to 32, in steps of 32][N rounded up to 256][32] (forward: reduction over K) and, transposed, [N rounded
+// up to 32, in steps of 32][K rounded up to 256][32] (backward-data: reduction over N), zero in the padding.  Step-major:
+// the 64 bytes that one reduction step needs of consecutive rows lie side by side, so a wave's 1 KB request covers
+// eight whole 128-byte lines (row-major planes cost sixteen half lines per request, and the vector memory path's time
+// goes by the line).  Layout of the buffer: forward h, forward l, transposed h, transposed l.
+struct PlaneDims { int64_t f_rows, f_ld, t_rows, t_ld; };     // rows and (rounded) reduction length, in f16 elements, of the two images
 static PlaneDims plane_dims(int N, int K) {
     return PlaneDims{ceil_div(N, 256) * 256, ceil_div(K, 32) * 32, ceil_div(K, 256) * 256, ceil_div(N, 32) * 32};
 }
@@ -1117,9 +1144,10 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitJobs jobs) {
     const SplitJob j = jobs.j[blockIdx.y];
     const float scale = split2_scale(*j.amax);
     // forward image: consecutive threads along k (coalesced reads and writes)
-    const int64_t nf = j.d.f_rows * j.d.f_ld;
+    const int64_t nf = j.d.f_rows * j.d.f_ld, per_step = j.d.f_rows * 32;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += (int64_t)gridDim.x * 256) {
-        const int64_t n = i / j.d.f_ld, k = i - n * j.d.f_ld;
+        const int64_t t = i / per_step, rem = i - t * per_step;
+        const int64_t n = rem >> 5, k = 32 * t + (rem & 31);
         const float x = (n < j.N && k < j.K) ? j.w[n * j.ld + k] : 0.f;
         _Float16 h, l;
         split2_one(x, scale, h, l);
@@ -1138,7 +1166,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitJobs jobs) {
             const float x = (n < j.N && k < j.K) ? j.w[n * j.ld + k] : 0.f;
             _Float16 h, l;
             split2_one(x, scale, h, l);
-            j.th[k * j.d.t_ld + n] = h; j.tl[k * j.d.t_ld + n] = l;
+            j.th[(nb * j.d.t_rows + k) * 32 + (lane & 31)] = h; j.tl[(nb * j.d.t_rows + k) * 32 + (lane & 31)] = l;
         }
     }
 }
@@ -1425,10 +1453,10 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
     if ((int64_t)p.gx * p.gy < kTileWgs) return DLRM_OK;
     const PlaneDims d = plane_dims(wp->N, wp->K);
     const unsigned char *base = static_cast<const unsigned char *>(wp->d_planes);
-    if (!transposed) { p.bp_h = base; p.bp_l = base + 2 * d.f_rows * d.f_ld; p.bp_ld = 2 * d.f_ld; }
+    if (!transposed) { p.bp_h = base; p.bp_l = base + 2 * d.f_rows * d.f_ld; p.bp_ld = 64 * d.f_rows; }
     else {
         base += 4 * d.f_rows * d.f_ld;
-        p.bp_h = base; p.bp_l = base + 2 * d.t_rows * d.t_ld; p.bp_ld = 2 * d.t_ld;
+        p.bp_h = base; p.bp_l = base + 2 * d.t_rows * d.t_ld; p.bp_ld = 64 * d.t_rows;
     }
     const dim3 grid((unsigned)(p.gx * p.gy)), block(kGemmThreads);
     const bool tail = p.K % 32 != 0;
@@ -1437,6 +1465,22 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
         if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4>), grid, block, 0, s, p);         \
         else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4>), grid, block, 0, s, p);             \
     } while (0)
+#ifdef DLRM_F16P_ABLATE
+    static const int abl = [] { const char *e = getenv("DLRM_F16P_ABLATE"); return e ? atoi(e) : 0; }();
+#define DLRM_F16P_ABL(V) case V: hipLaunchKernelGGL((gemm_f16p_kernel<false, true, true, 4, V>), grid, block, 0, s, p); break;
+    if (abl != 0 && !tail) {
+        switch (abl) {
+        DLRM_F16P_ABL(1) DLRM_F16P_ABL(2) DLRM_F16P_ABL(4) DLRM_F16P_ABL(16) DLRM_F16P_ABL(5) DLRM_F16P_ABL(18) DLRM_F16P_ABL(7)
+        DLRM_F16P_ABL(23) DLRM_F16P_ABL(32) DLRM_F16P_ABL(64)
+        case 1000: hipLaunchKernelGGL((gemm_f16p_kernel<false, true, true, 4, 0, 3>), grid, block, 0, s, p); break;
+        default: return DLRM_ERR_INVALID;
+        }
+        DLRM_LAUNCH_CHECK();
+        *done = true;
+        return DLRM_OK;
+    }
+#undef DLRM_F16P_ABL
+#endif
     switch (path) {
     case 0: DLRM_F16P_LAUNCH(true, true); break;
     case 1: DLRM_F16P_LAUNCH(false, true); break;
