@@ -228,7 +228,10 @@ __device__ inline void load_grad(const float *g, float (&v)[NF]) {
 // Runs of equal keys are cut at multiples of kSegLen sorted positions, so no group ever sums
 // more than kSegLen gradient rows: a table of 3 rows hit by a 65536-sample batch is 20000-long
 // runs, which one group would otherwise walk alone.
-constexpr int kSegLen = 128;
+#ifndef DLRM_BWD_SEGLEN
+#define DLRM_BWD_SEGLEN 128      // (256: measured equal at the MLPerf shape)
+#endif
+constexpr int kSegLen = DLRM_BWD_SEGLEN;
 
 template <int NF>
 __device__ inline void load_vec(const float *g, float (&v)[NF]) { load_grad<NF>(g, v); }
@@ -324,7 +327,10 @@ __device__ inline const float *occurrence(const BwdParams &p, uint32_t g, float 
 //    runs: every group of every workgroup sums its share.
 // DLRM_DUP_LAST_WINS: only the last occurrence of a row counts, so every position is its own run and
 // only run ends are applied.
-constexpr int kChunk = 4;
+#ifndef DLRM_BWD_CHUNK
+#define DLRM_BWD_CHUNK 4         // (8: 110 registers, four waves per SIMD instead of six: measured 15% slower)
+#endif
+constexpr int kChunk = DLRM_BWD_CHUNK;
 
 template <typename IDX, typename KEY, typename ROW, int VEC16, int G, int NC>
 __global__ __launch_bounds__(kBwdThreads) void sparse_update_kernel(BwdParams p, const KEY *__restrict__ keys,
