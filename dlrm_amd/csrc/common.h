@@ -121,6 +121,12 @@ int interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x0, int
                                     float *d_x_copy, float *d_out_max, dlrm_stream_t stream);
 int interact_dot_backward_max(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F, int32_t D,
                               float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max, dlrm_stream_t stream);
+// ... and the same for the kernels that read / write the features through views
+int interact_dot_forward_views_max(const dlrm_feature_view *x_views, int64_t B, int32_t F, int32_t D, float *d_out, int64_t out_ld,
+                                   float *d_out_max, dlrm_stream_t stream);
+int interact_dot_backward_views_max(const dlrm_feature_view *x_views, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F,
+                                    int32_t D, const dlrm_feature_view *dx_views, int32_t relu_mask_feature0, float *d_dx0_max,
+                                    dlrm_stream_t stream);
 
 // Folds the largest magnitude a wave has seen (per-lane `vmax` >= 0) into *slot: one wave reduction, at most one atomic
 // per wave and only if it can still raise the slot (thousands of atomics on one address queue up behind each other;

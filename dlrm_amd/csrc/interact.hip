@@ -451,7 +451,8 @@ __device__ inline void views_fetch(float *const *__restrict__ sb, const int64_t 
 
 template <int NV>
 __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_views_kernel(Views xv, int64_t B, int F, int D,
-                                                                              float *__restrict__ out, int64_t out_ld) {
+                                                                              float *__restrict__ out, int64_t out_ld,
+                                                                              float *__restrict__ out_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = D + 4;
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_views_kernel(
     const int64_t stride = (int64_t)gridDim.x * kIntWaves;
     int64_t b = (int64_t)blockIdx.x * kIntWaves + wave;
     f32x4 pre[NV];
+    float vmax = 0.f;
     views_fetch<NV>(sb, sst, b < B ? b : 0, n4, D, ld, lane, pre);
     for (; b < B; b += stride) {
         gather_park<NV>(sx, n4, D, ld, lane, pre);
@@ -472,20 +474,21 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_views_kernel(
         __builtin_amdgcn_wave_barrier();
         views_fetch<NV>(sb, sst, b + stride < B ? b + stride : b, n4, D, ld, lane, pre);
         __builtin_amdgcn_sched_barrier(0);
-        float unused = 0.f;
-        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane, unused);
+        fwd_sample(sx, F, D, ld, out + b * out_ld, out_ld, lane, vmax);
         __builtin_amdgcn_wave_barrier();
     }
+    if (out_max != nullptr) fold_absmax_block(vmax, out_max);
 }
 
 template <int NV>
 __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_views_kernel(Views xv, Views dv, const float *__restrict__ dout,
                                                                               int64_t dout_ld, int64_t B, int F, int D,
-                                                                              int relu_mask0) {
+                                                                              int relu_mask0, float *__restrict__ dx0_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = D + 4;
     const int per_wave = F * ld + F * kSLd + 4;
+    float vmax0 = 0.f;
     float *sx = smem + (size_t)wave * per_wave;
     float *ss = sx + F * ld;
     float **sb = reinterpret_cast<float **>(smem + (size_t)kIntWaves * per_wave);
@@ -544,8 +547,7 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_views_kernel(
             int lds_off[NV];   // (unused by a bwd_sample that leaves the store to its caller)
 #pragma unroll
             for (int u = 0; u < NV; u++) lds_off[u] = 0;
-            float unused = 0.f;
-            bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane, unused);
+            bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane, vmax0);
         }
         {   // every feature's gradient to its own place
             const int lv = opaque(lane);
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_views_kernel(
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (dx0_max != nullptr) fold_absmax_block(vmax0, dx0_max);
 }
 
 }  // namespace dlrm
@@ -715,6 +718,12 @@ static int check_views(const dlrm_feature_view *v, int32_t F, int32_t D, const c
 
 extern "C" int dlrm_interact_dot_forward_views(const dlrm_feature_view *x_views, int64_t B, int32_t F, int32_t D, float *d_out,
                                                int64_t out_ld, dlrm_stream_t stream) {
+    return dlrm::interact_dot_forward_views_max(x_views, B, F, D, d_out, out_ld, nullptr, stream);
+}
+
+// d_out_max (may be NULL): max |out| is folded into it (atomic max on the float's bits: zero it first)
+int dlrm::interact_dot_forward_views_max(const dlrm_feature_view *x_views, int64_t B, int32_t F, int32_t D, float *d_out,
+                                         int64_t out_ld, float *d_out_max, dlrm_stream_t stream) {
     DLRM_REQUIRE(B >= 0 && F >= 1 && F <= kFP && D >= 8 && (D & (D - 1)) == 0 && F * D <= 4096,
                  "views need 1 <= F <= %d, dim a power of two >= 8, F*dim <= 4096; got F=%d dim=%d", kFP, F, D);
     if (B == 0) return DLRM_OK;
@@ -730,7 +739,7 @@ extern "C" int dlrm_interact_dot_forward_views(const dlrm_feature_view *x_views,
         DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_fwd_views_kernel<NV>),                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
         hipLaunchKernelGGL(interact_dot_fwd_views_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), \
-                           xv, B, F, D, d_out, out_ld);                                                                \
+                           xv, B, F, D, d_out, out_ld, d_out_max);                                                     \
         break;
     switch (nv) {
         DLRM_INT_FWDV(1) DLRM_INT_FWDV(2) DLRM_INT_FWDV(3) DLRM_INT_FWDV(4) DLRM_INT_FWDV(5) DLRM_INT_FWDV(6) DLRM_INT_FWDV(7)
@@ -746,6 +755,13 @@ extern "C" int dlrm_interact_dot_forward_views(const dlrm_feature_view *x_views,
 extern "C" int dlrm_interact_dot_backward_views(const dlrm_feature_view *x_views, const float *d_dout, int64_t dout_ld, int64_t B,
                                                 int32_t F, int32_t D, const dlrm_feature_view *dx_views,
                                                 int32_t relu_mask_feature0, dlrm_stream_t stream) {
+    return dlrm::interact_dot_backward_views_max(x_views, d_dout, dout_ld, B, F, D, dx_views, relu_mask_feature0, nullptr, stream);
+}
+
+// d_dx0_max (may be NULL): max |gradient of feature 0| is folded into it
+int dlrm::interact_dot_backward_views_max(const dlrm_feature_view *x_views, const float *d_dout, int64_t dout_ld, int64_t B,
+                                          int32_t F, int32_t D, const dlrm_feature_view *dx_views, int32_t relu_mask_feature0,
+                                          float *d_dx0_max, dlrm_stream_t stream) {
     DLRM_REQUIRE(B >= 0 && F >= 1 && F <= kFP && D >= 8 && (D & (D - 1)) == 0 && F * D <= 4096,
                  "views need 1 <= F <= %d, dim a power of two >= 8, F*dim <= 4096; got F=%d dim=%d", kFP, F, D);
     if (B == 0) return DLRM_OK;
@@ -762,7 +778,7 @@ extern "C" int dlrm_interact_dot_backward_views(const dlrm_feature_view *x_views
         DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_views_kernel<NV>),                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
         hipLaunchKernelGGL(interact_dot_bwd_views_kernel<NV>, dim3(blocks), dim3(kIntThreads), lds, as_stream(stream), \
-                           xv, dv, d_dout, dout_ld, B, F, D, relu_mask_feature0);                                      \
+                           xv, dv, d_dout, dout_ld, B, F, D, relu_mask_feature0, d_dx0_max);                           \
         break;
     switch (nv) {
         DLRM_INT_BWDV(1) DLRM_INT_BWDV(2) DLRM_INT_BWDV(3) DLRM_INT_BWDV(4) DLRM_INT_BWDV(5) DLRM_INT_BWDV(6) DLRM_INT_BWDV(7)

@@ -433,8 +433,10 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
         if (int rc = wait_for(m, main, emb)) return rc;
         if (m->dot)
             if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
-                    if (m->views)
-                        return dlrm_interact_dot_forward_views(m->x_views.data(), m->B, m->F, m->D, m->inter, m->inter_ld, main);
+                    if (m->views) {
+                        float *out_max = big_layer(m, m->topl[0]) ? out_slot(m, m->topl[0].s_x) : nullptr;
+                        return interact_dot_forward_views_max(m->x_views.data(), m->B, m->F, m->D, m->inter, m->inter_ld, out_max, main);
+                    }
                     return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main);
                 }))
                 return rc;
@@ -914,10 +916,10 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
         if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, m->dinter, m->inter_ld, main))
             return rc;
         if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_BACKWARD, main, [&] {
-                if (m->views)   // gradients straight into the send blocks of the backward exchange
-                    return dlrm_interact_dot_backward_views(m->x_views.data(), m->dinter, m->inter_ld, m->B, m->F, m->D,
-                                                            m->dx_views.data(), 1, main);
                 float *dx0_max = big_layer(m, m->bot.back()) ? out_slot(m, m->bot.back().s_dz) : nullptr;
+                if (m->views)   // gradients straight into the send blocks of the backward exchange
+                    return interact_dot_backward_views_max(m->x_views.data(), m->dinter, m->inter_ld, m->B, m->F, m->D,
+                                                           m->dx_views.data(), 1, dx0_max, main);
                 return interact_dot_backward_max(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, dx0_max, main);
             }))
             return rc;
