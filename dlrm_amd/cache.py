@@ -155,6 +155,11 @@ class EmbeddingCache:
         """Pages used in the last `age` lookup calls are never evicted by the reclaims that follow."""
         check(self.L.dlrm_cache_set_protect_age(self.h, int(age)))
 
+    def set_async_writeback(self, max_pages):
+        """A reclaim with at most max_pages victims parks them in HBM and lets a stream of the cache's own carry them
+        to the store beside the next lookup's misses (0: write back inside the reclaim, the default)."""
+        check(self.L.dlrm_cache_set_async_writeback(self.h, C.c_int64(int(max_pages)), self._stream()))
+
     def mark_dirty(self, rows):
         """rows: what get_emb_vectors returned for ids whose rows are about to be updated."""
         dt = _capi.I32 if rows.dtype == torch.int32 else _capi.I64

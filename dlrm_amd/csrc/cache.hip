@@ -82,6 +82,11 @@ struct CacheDev {
     char *data;
     float *state;          // [S * vpo] the rows' optimizer state, moved with their pages; NULL = none
     int64_t S;
+    // asynchronous write-back (all NULL unless enabled): victims are parked here before their slots are released
+    uint32_t *pending;     // one bit per page: parked by the last reclaim, its way to the store may not be over
+    char *stage_data;      // [stage_cap] pages
+    float *stage_state;    // [stage_cap * vpo]
+    int32_t *stage_gp;     // [stage_cap] page of a parked entry, -1 = nothing to write
 };
 
 }  // namespace dlrm
@@ -101,6 +106,10 @@ struct dlrm_cache {
     bool owns_state;
     int protect_age;         // pages used in the last protect_age lookup calls are never victims
     int reclaim_table;       // table of a pending single-table reclaim, -1 = every table
+    int64_t stage_cap;       // pages the parking area holds; 0 = victims are written back inside the reclaim
+    hipStream_t wb_stream;   // carries parked pages to the store
+    hipEvent_t wb_ready, wb_done;
+    bool wb_recorded;        // wb_done has been recorded at least once
 };
 
 namespace dlrm {
@@ -226,7 +235,15 @@ __device__ inline int64_t valid_page_bytes(const TableGeom &g, int t, int64_t pa
 
 // backing store -> slot: the device read replaces nvm_cmd_read + decode (emb_cache.cpp:451-497).
 // One lane moves 16 bytes; a page is covered by consecutive lanes (coalesced on both sides).
-__global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheDev d) {
+// phase -1: every missed page; 0: those whose page is not on its way to the store; 1: those that are (launched
+// once that write-back has ended)
+__device__ inline bool fill_now(const CacheDev &d, int64_t gp, int phase) {
+    if (phase < 0) return true;
+    const bool pending = (d.pending[gp >> 5] >> (gp & 31)) & 1u;
+    return pending == (phase == 1);
+}
+
+__global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheDev d, int phase) {
     const int64_t n_miss = d.scalars[S_N_MISS];
     const int64_t avail = d.scalars[S_TAIL] - d.scalars[S_HEAD];
     const int64_t n = n_miss < avail ? n_miss : avail;
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheD
          w += (int64_t)gridDim.x * kCacheThreads) {
         const int64_t i = w / chunks, c = w - i * chunks;
         const int64_t gp = d.miss_sorted[i];
+        if (!fill_now(d, gp, phase)) continue;
         const int t = table_of_page(g, gp);
         const int64_t page = gp - g.page_base[t];
         if (c * 16 < valid_page_bytes(g, t, page)) {
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(kCacheThreads) void fill_kernel(TableGeom g, CacheD
          w += (int64_t)gridDim.x * kCacheThreads) {
         const int64_t i = w / g.vpo, r = w - i * g.vpo;
         const int64_t gp = d.miss_sorted[i];
+        if (!fill_now(d, gp, phase)) continue;
         const int t = table_of_page(g, gp);
         const int64_t row = (gp - g.page_base[t]) * g.vpo + r;
         if (row < g.rows[t]) d.state[(int64_t)d.page_map[gp] * g.vpo + r] = g.state_store[t][row];
@@ -477,6 +496,66 @@ __global__ __launch_bounds__(kCacheThreads) void writeback_victims_kernel(TableG
     }
 }
 
+// Asynchronous write-back, first half (on the reclaim's stream, HBM to HBM): victim number `pos` is parked in entry
+// `pos` of the parking area and its page is flagged as on its way, so its slot can be released at once.
+__global__ __launch_bounds__(kCacheThreads) void park_victims_kernel(TableGeom g, CacheDev d, int64_t n_cand,
+                                                                      const int32_t *cand_pos) {
+    const int64_t chunks = g.page_bytes / 16;
+    const int64_t total = n_cand * chunks;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / chunks, c = w - i * chunks;
+        const int64_t pos = cand_pos[i];
+        if (pos < 0) continue;
+        const int32_t s = d.cand_val_sorted[i];
+        if (d.dirty_only && !d.slot_dirty[s]) continue;   // the store already holds these rows (the entry stays -1)
+        const int64_t gp = (int64_t)(uint32_t)d.cand_key_sorted[i];
+        if (c == 0) {
+            d.stage_gp[pos] = (int32_t)gp;
+            atomicOr(&d.pending[gp >> 5], 1u << (gp & 31));
+        }
+        *reinterpret_cast<uint4 *>(d.stage_data + pos * g.page_bytes + c * 16) =
+            *reinterpret_cast<const uint4 *>(d.data + (int64_t)s * g.page_bytes + c * 16);
+    }
+    if (!g.has_state) return;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < n_cand * g.vpo;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t i = w / g.vpo, r = w - i * g.vpo;
+        const int64_t pos = cand_pos[i];
+        if (pos < 0) continue;
+        const int32_t s = d.cand_val_sorted[i];
+        if (d.dirty_only && !d.slot_dirty[s]) continue;
+        d.stage_state[pos * g.vpo + r] = d.state[(int64_t)s * g.vpo + r];
+    }
+}
+
+// ... second half (on the cache's own stream, beside whatever the caller enqueues next): parked pages to the store
+__global__ __launch_bounds__(kCacheThreads) void writeback_parked_kernel(TableGeom g, CacheDev d, int64_t n_parked) {
+    const int64_t chunks = g.page_bytes / 16;
+    const int64_t total = n_parked * chunks;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t pos = w / chunks, c = w - pos * chunks;
+        const int64_t gp = d.stage_gp[pos];
+        if (gp < 0) continue;
+        const int t = table_of_page(g, gp);
+        const int64_t page = gp - g.page_base[t];
+        if (c * 16 < valid_page_bytes(g, t, page))
+            *reinterpret_cast<uint4 *>(g.store[t] + page * g.page_bytes + c * 16) =
+                *reinterpret_cast<const uint4 *>(d.stage_data + pos * g.page_bytes + c * 16);
+    }
+    if (!g.has_state) return;
+    for (int64_t w = (int64_t)blockIdx.x * kCacheThreads + threadIdx.x; w < n_parked * g.vpo;
+         w += (int64_t)gridDim.x * kCacheThreads) {
+        const int64_t pos = w / g.vpo, r = w - pos * g.vpo;
+        const int64_t gp = d.stage_gp[pos];
+        if (gp < 0) continue;
+        const int t = table_of_page(g, gp);
+        const int64_t row = (gp - g.page_base[t]) * g.vpo + r;
+        if (row < g.rows[t]) g.state_store[t][row] = d.stage_state[pos * g.vpo + r];
+    }
+}
+
 __global__ __launch_bounds__(kCacheThreads) void evict_kernel(TableGeom g, CacheDev d, int64_t n_cand,
                                                                const int32_t *cand_pos) {
     const uint32_t now = (uint32_t)d.scalars[S_EPOCH];
@@ -571,6 +650,14 @@ __global__ void init_ring_kernel(CacheDev d) {
         d.slot_epoch[i] = 0;
         d.slot_dirty[i] = 0;
     }
+}
+
+// workgroups of the kernels that move pages over the host link (tuning aids: DLRM_CACHE_FILL_BLOCKS, DLRM_CACHE_WB_BLOCKS)
+static unsigned link_blocks(bool writeback) {
+    static const int fill = [] { const char *e = getenv("DLRM_CACHE_FILL_BLOCKS"); return e ? atoi(e) : kLinkBlocks; }();
+    static const int wb = [] { const char *e = getenv("DLRM_CACHE_WB_BLOCKS"); return e ? atoi(e) : kLinkBlocks; }();
+    const int v = writeback ? wb : fill;
+    return (unsigned)(v < 1 ? 1 : v > 4096 ? 4096 : v);
 }
 
 static unsigned grid_for(int64_t n) {
@@ -748,6 +835,13 @@ extern "C" int dlrm_cache_destroy(dlrm_cache *c) {
     (void)hipFree(d.page_map); (void)hipFree(d.slot_gp); (void)hipFree(d.slot_epoch); (void)hipFree(d.slot_dirty); (void)hipFree(d.ring); (void)hipFree(d.scalars);
     (void)hipFree(d.counters); (void)hipFree(d.k_t); (void)hipFree(d.thr_age); (void)hipFree(d.hist); (void)hipFree(d.miss); (void)hipFree(d.miss_sorted);
     (void)hipFree(d.cand_key); (void)hipFree(d.cand_key_sorted); (void)hipFree(d.cand_val); (void)hipFree(d.cand_val_sorted);
+    if (c->wb_stream) {
+        (void)hipStreamSynchronize(c->wb_stream);
+        (void)hipStreamDestroy(c->wb_stream);
+        (void)hipEventDestroy(c->wb_ready);
+        (void)hipEventDestroy(c->wb_done);
+    }
+    (void)hipFree(d.pending); (void)hipFree(d.stage_data); (void)hipFree(d.stage_state); (void)hipFree(d.stage_gp);
     if (c->owns_pool) (void)hipFree(d.data);
     if (c->owns_state) (void)hipFree(d.state);
     (void)hipFree(c->sort_tmp);
@@ -806,7 +900,15 @@ extern "C" int dlrm_cache_lookup(dlrm_cache *c, const void *d_ids, int32_t idx_d
     DLRM_HIP(rocprim::radix_sort_keys(c->sort_tmp, tmp, c->d.miss, c->d.miss_sorted, (size_t)n, 0u, (unsigned)bits, s,
                                       false));
     hipLaunchKernelGGL(assign_kernel, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d);
-    hipLaunchKernelGGL(fill_kernel, dim3(kLinkBlocks), dim3(kCacheThreads), 0, s, c->g, c->d);
+    if (c->stage_cap > 0 && c->wb_recorded) {
+        // pages that are not on their way to the store cross the link now, beside that write-back; the few that are
+        // (evicted by the last reclaim and wanted again already) once it has ended
+        hipLaunchKernelGGL(fill_kernel, dim3(link_blocks(false)), dim3(kCacheThreads), 0, s, c->g, c->d, 0);
+        DLRM_HIP(hipStreamWaitEvent(s, c->wb_done, 0));
+        hipLaunchKernelGGL(fill_kernel, dim3(link_blocks(false)), dim3(kCacheThreads), 0, s, c->g, c->d, 1);
+    } else {
+        hipLaunchKernelGGL(fill_kernel, dim3(link_blocks(false)), dim3(kCacheThreads), 0, s, c->g, c->d, -1);
+    }
     if (idx_dtype == DLRM_I64)
         hipLaunchKernelGGL(translate_kernel<int64_t>, dim3(grid_for(n)), dim3(kCacheThreads), 0, s, c->g, c->d, l,
                            static_cast<const int64_t *>(d_ids), n, static_cast<int64_t *>(d_rows_out));
@@ -842,6 +944,12 @@ extern "C" int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream) {
     c->reclaim_pending = false;
     const int64_t passes = c->h_reclaim[S_PASSES], n_cand = c->h_reclaim[S_N_CAND];
     if (passes == 0) return DLRM_OK;
+    // victims of this reclaim: at most passes * evict_group per table
+    const int64_t most = passes * c->g.ws * (c->reclaim_table >= 0 ? 1 : c->g.T);
+    const bool park = c->stage_cap > 0 && n_cand > 0 && most <= c->stage_cap;
+    if (c->wb_recorded) DLRM_HIP(hipStreamWaitEvent(s, c->wb_done, 0));   // the parking area and the flags are free again
+    if (c->stage_cap > 0) DLRM_HIP(hipMemsetAsync(c->d.pending, 0, sizeof(uint32_t) * (size_t)ceil_div(c->total_pages, 32), s));
+    if (park) DLRM_HIP(hipMemsetAsync(c->d.stage_gp, 0xff, sizeof(int32_t) * (size_t)most, s));
     if (n_cand > 0) {
         size_t tmp = 0;
         DLRM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c->d.cand_key, c->d.cand_key_sorted, c->d.cand_val,
@@ -853,13 +961,57 @@ extern "C" int dlrm_cache_reclaim_finish(dlrm_cache *c, dlrm_stream_t stream) {
         int32_t *cand_pos = c->d.cand_val;  // the unsorted value buffer is free once the sort is done
         hipLaunchKernelGGL(rank_victims_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
-        hipLaunchKernelGGL(writeback_victims_kernel, dim3(kLinkBlocks), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
-                           cand_pos);
+        if (park)
+            hipLaunchKernelGGL(park_victims_kernel, dim3(grid_for(n_cand * (c->g.page_bytes / 16))), dim3(kCacheThreads), 0, s,
+                               c->g, c->d, n_cand, cand_pos);
+        else
+            hipLaunchKernelGGL(writeback_victims_kernel, dim3(link_blocks(true)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
+                               cand_pos);
         hipLaunchKernelGGL(evict_kernel, dim3(grid_for(n_cand)), dim3(kCacheThreads), 0, s, c->g, c->d, n_cand,
                            cand_pos);
     }
     hipLaunchKernelGGL(finish_reclaim_kernel, dim3(1), dim3(1), 0, s, c->g, c->d, c->reclaim_table);
     DLRM_LAUNCH_CHECK();
+    if (park) {
+        DLRM_HIP(hipEventRecord(c->wb_ready, s));
+        DLRM_HIP(hipStreamWaitEvent(c->wb_stream, c->wb_ready, 0));
+        hipLaunchKernelGGL(writeback_parked_kernel, dim3(link_blocks(true)), dim3(kCacheThreads), 0, c->wb_stream, c->g, c->d, most);
+        DLRM_LAUNCH_CHECK();
+        DLRM_HIP(hipEventRecord(c->wb_done, c->wb_stream));
+        c->wb_recorded = true;
+    }
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_cache_set_async_writeback(dlrm_cache *c, int64_t max_pages, dlrm_stream_t stream) {
+    DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    DLRM_REQUIRE(max_pages >= 0, "max_pages < 0");
+    DLRM_REQUIRE(!c->reclaim_pending, "a reclaim is pending: call dlrm_cache_reclaim_finish first");
+    hipStream_t s = as_stream(stream);
+    if (c->wb_stream) DLRM_HIP(hipStreamSynchronize(c->wb_stream));   // nothing is on its way any more
+    DLRM_HIP(hipStreamSynchronize(s));
+    c->wb_recorded = false;
+    (void)hipFree(c->d.pending); (void)hipFree(c->d.stage_data); (void)hipFree(c->d.stage_state); (void)hipFree(c->d.stage_gp);
+    c->d.pending = nullptr; c->d.stage_data = nullptr; c->d.stage_state = nullptr; c->d.stage_gp = nullptr;
+    c->stage_cap = 0;
+    if (max_pages == 0) return DLRM_OK;
+    if (!c->wb_stream) {
+        DLRM_HIP(hipStreamCreateWithFlags(&c->wb_stream, hipStreamNonBlocking));
+        DLRM_HIP(hipEventCreateWithFlags(&c->wb_ready, hipEventDisableTiming));
+        DLRM_HIP(hipEventCreateWithFlags(&c->wb_done, hipEventDisableTiming));
+    }
+    const size_t words = (size_t)ceil_div(c->total_pages, 32);
+    int rc = dev_alloc(&c->d.pending, words);
+    if (!rc) rc = dev_alloc(&c->d.stage_data, (size_t)max_pages * (size_t)c->g.page_bytes);
+    if (!rc) rc = dev_alloc(&c->d.stage_gp, (size_t)max_pages);
+    if (!rc && c->g.has_state) rc = dev_alloc(&c->d.stage_state, (size_t)max_pages * (size_t)c->g.vpo);
+    if (rc) {
+        (void)hipFree(c->d.pending); (void)hipFree(c->d.stage_data); (void)hipFree(c->d.stage_state); (void)hipFree(c->d.stage_gp);
+        c->d.pending = nullptr; c->d.stage_data = nullptr; c->d.stage_state = nullptr; c->d.stage_gp = nullptr;
+        return rc;
+    }
+    DLRM_HIP(hipMemset(c->d.pending, 0, sizeof(uint32_t) * words));
+    c->stage_cap = max_pages;
     return DLRM_OK;
 }
 
@@ -905,6 +1057,7 @@ extern "C" int dlrm_cache_mark_dirty(dlrm_cache *c, const void *d_rows, int32_t 
 
 extern "C" int dlrm_cache_flush(dlrm_cache *c, dlrm_stream_t stream) {
     DLRM_REQUIRE(c != nullptr, "cache is NULL");
+    if (c->wb_recorded) DLRM_HIP(hipStreamWaitEvent(as_stream(stream), c->wb_done, 0));   // the store is whole behind this call
     hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(kCacheThreads), 0, as_stream(stream), c->g, c->d);
     hipLaunchKernelGGL(clear_dirty_kernel, dim3(grid_for(c->d.S)), dim3(256), 0, as_stream(stream), c->d);
     DLRM_LAUNCH_CHECK();

@@ -260,6 +260,8 @@ class DLRM:
                 self.cache = EmbeddingCache(rows, D, cache_pages, cache_pages + headroom, rows_per_page=rpp,
                                             row_dtype=wdtype, device=dev, dirty_only=True, row_state=adagrad,
                                             max_lookup_ids=2 * max(self.Tl * self.Bg * cfg.lookups, 1))
+                # victims travel to the store beside the next batch's misses (both directions of the host link at once)
+                self.cache.set_async_writeback(headroom)
                 if init_tables:
                     self.cache.write(seed, table_ids=self.local_table_ids)
             else:

@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1015
+#define DLRM_ABI_VERSION 1016
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -608,6 +608,19 @@ int dlrm_cache_reclaim_table(dlrm_cache *c, int32_t table, dlrm_stream_t stream)
  * (the reverse of src/dlrmtest.cpp:484-494) sets 1: the rows batch n+1 will pool from must stay.
  */
 int dlrm_cache_set_protect_age(dlrm_cache *c, int32_t age);
+/*
+ * Victims travel to the store BESIDE the calls that follow a reclaim instead of inside it (the reference writes a
+ * victim page in Reclaim_vector_page, src/emb_cache.cpp:259-305, before get_emb_vectors reads the next batch's
+ * misses, :451-512: one direction of the link at a time).  max_pages > 0: a reclaim with at most that many victims
+ * (passes * evict_group * tables) parks them in an HBM area of max_pages pages -- its slots are free at once -- and a
+ * stream of the cache's own writes the area to the store; the next lookup brings in its misses meanwhile, except
+ * pages that are still on their way (flagged per page), which it fills once that write-back has ended.  Larger
+ * reclaims write back inside the call as before.  dlrm_cache_flush and dlrm_cache_destroy wait for the write-back,
+ * so the store is whole behind a flush; a host that reads the store directly must flush first.  Residency, eviction
+ * order, slot assignment and all counters are the same in both modes.  max_pages = 0 (the default) turns it off.
+ * Synchronises (stream and the cache's own); allocates.  All calls of one cache go to one stream, as before.
+ */
+int dlrm_cache_set_async_writeback(dlrm_cache *c, int64_t max_pages, dlrm_stream_t stream);
 /*
  * The slot-pool rows d_rows[0..n) (what dlrm_cache_lookup returned; negative entries are skipped) are about to
  * be updated: their pages will be copied back when they leave the cache.  Stands in for the reference's

@@ -41,8 +41,11 @@ def compare_state(cache, pc, T):
         assert np.array_equal(got, ref[:got.size]) and (ref[got.size:] == -1).all(), "slot map of table %d" % t
 
 
+# async_wb: victims parked in HBM and written to the store by the cache's own stream beside the next lookup
+# (dlrm_cache_set_async_writeback); 40 pages: some reclaims fit the parking area, larger ones write back in the call
+@pytest.mark.parametrize("async_wb", [0, 10 ** 4, 40], ids=["wb-in-reclaim", "wb-async", "wb-async-small-area"])
 @pytest.mark.parametrize("dim,vpo,idx_t", [(32, None, torch.int64), (128, 1, torch.int32), (16, 4, torch.int64)])
-def test_cache_matches_oracle_state_machine(oracle, dim, vpo, idx_t):
+def test_cache_matches_oracle_state_machine(oracle, dim, vpo, idx_t, async_wb):
     from dlrm_amd.cache import EmbeddingCache
     rng = np.random.default_rng(dim)
     rows = [1000, 37, 5000, 64]          # unequal tables; the oracle takes one size: pad to the largest
@@ -50,6 +53,7 @@ def test_cache_matches_oracle_state_machine(oracle, dim, vpo, idx_t):
     n_slots, cap, ws = 700, 300, 8
     cache = EmbeddingCache(rows, dim, cache_size=cap, num_slots=n_slots, rows_per_page=vpo, evict_group=ws)
     cache.write(seed=3)
+    cache.set_async_writeback(async_wb)
     page_bytes = cache.vpo * dim * 4
     pc = oracle.PageCache(T, max(rows), dim, cache_size=cap, page_bytes=page_bytes, ws_opt=ws, n_slots=n_slots)
     assert pc.vpo == cache.vpo
@@ -174,8 +178,9 @@ def test_reclaim_of_one_table_matches_oracle(oracle):
     cache.close()
 
 
+@pytest.mark.parametrize("async_wb", [0, 10 ** 4], ids=["wb-in-reclaim", "wb-async"])
 @pytest.mark.parametrize("vpo", [1, 8])
-def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo):
+def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo, async_wb):
     """writeback_dirty_only: residency, eviction order and the reference's counters are unchanged; only pages
     marked dirty since they were read are copied back (counter 6), and the store still ends up with every update."""
     from dlrm_amd.cache import EmbeddingCache
@@ -186,6 +191,7 @@ def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo):
     cache = EmbeddingCache(rows, dim, cache_size=cap, num_slots=n_slots, rows_per_page=vpo, evict_group=ws,
                            dirty_only=True, max_lookup_ids=4 * 200)
     cache.write(seed=3)
+    cache.set_async_writeback(async_wb)
     pc = oracle.PageCache(T, max(rows), dim, cache_size=cap, page_bytes=vpo * dim * 4, ws_opt=ws, n_slots=n_slots)
     pc.set_dirty_only(True)
     expect = [s.copy() for s in cache.store]
@@ -214,9 +220,10 @@ def test_dirty_only_writeback_matches_oracle_and_store(oracle, vpo):
     cache.close()
 
 
+@pytest.mark.parametrize("async_wb", [0, 10 ** 4], ids=["wb-in-reclaim", "wb-async"])
 @pytest.mark.parametrize("vpo", [1, 4])
 @pytest.mark.parametrize("dirty_only", [False, True])
-def test_row_state_travels_with_its_page(vpo, dirty_only):
+def test_row_state_travels_with_its_page(vpo, dirty_only, async_wb):
     """h_row_state_store: one float per row (an optimizer's state) is read into the pool's state array with the
     row's page and written back with it; exact bookkeeping of increments through many evictions."""
     from dlrm_amd.cache import EmbeddingCache
@@ -226,6 +233,7 @@ def test_row_state_travels_with_its_page(vpo, dirty_only):
     cache = EmbeddingCache(rows, dim, cache_size=120, num_slots=900, rows_per_page=vpo, evict_group=8,
                            dirty_only=dirty_only, max_lookup_ids=3 * 150, row_state=True)
     cache.write(seed=1)
+    cache.set_async_writeback(async_wb)
     for t in range(T):
         cache.state_store[t][:] = np.arange(rows[t], dtype=np.float32) + 1000.0 * t
     expect = [s.copy() for s in cache.state_store]
@@ -246,4 +254,41 @@ def test_row_state_travels_with_its_page(vpo, dirty_only):
     torch.cuda.synchronize()
     for t in range(T):
         assert np.array_equal(cache.state_store[t], expect[t]), "state of table %d" % t
+    cache.close()
+
+
+@pytest.mark.parametrize("vpo", [1, 8])
+def test_async_writeback_pages_wanted_again_at_once(vpo):
+    """Every batch evicts what the batch before brought in and asks for much of it again: most misses of a lookup are
+    pages still on their way to the store.  They must come back with the values they left with, batch after batch,
+    and the store must end up with every update."""
+    from dlrm_amd.cache import EmbeddingCache
+    rng = np.random.default_rng(77 + vpo)
+    rows, dim = [4096, 4096], 64
+    n = 1500
+    cache = EmbeddingCache(rows, dim, cache_size=16, num_slots=2 * 2 * n + 64, rows_per_page=vpo, evict_group=8)
+    cache.write(seed=5)
+    cache.set_async_writeback(2 * 2 * n + 64)
+    expect = [s.copy() for s in cache.store]
+    prev = None
+    for step in range(10):
+        per = []
+        for t in range(2):
+            fresh = rng.integers(0, rows[t], size=n // 3)
+            again = prev[t][rng.integers(0, prev[t].size, size=n - n // 3)] if prev is not None else rng.integers(0, rows[t], size=n - n // 3)
+            per.append(np.sort(np.concatenate([fresh, again])))
+        prev = per
+        ids = np.concatenate(per).astype(np.int64)
+        offs = [0, n, 2 * n]
+        got = cache.get_emb_vectors(torch.from_numpy(ids).cuda(), offs)
+        for t in range(2):
+            seg = ids[offs[t]:offs[t + 1]]
+            assert np.array_equal(cache.pool[got[offs[t]:offs[t + 1]].long()].cpu().numpy(), expect[t][seg]), (step, t)
+            expect[t][np.unique(seg)] += float(step + 1)
+        cache.pool[torch.unique(got.long())] += float(step + 1)
+        cache.reclaim()                 # capacity 16 pages: (nearly) everything leaves
+    assert cache.state().error_flags & ~4 == 0 and cache.counters()["evicted"].sum() > 4 * n // vpo
+    cache.flush()
+    for t in range(2):
+        assert np.array_equal(cache.store[t], expect[t]), "store of table %d" % t
     cache.close()

@@ -21,12 +21,14 @@ from dlrm_amd.cache import EmbeddingCache  # noqa: E402
 from dlrm_amd.data import zipf_ids  # noqa: E402
 
 
-def run(T, rows, D, B, steps, warm, frac, rows_per_page, alpha, dist):
+def run(T, rows, D, B, steps, warm, frac, rows_per_page, alpha, dist, wb="async"):
     total_pages = T * ((rows + rows_per_page - 1) // rows_per_page)
     cache_pages = int(total_pages * frac)
     headroom = min(total_pages, T * B)                       # a batch can bring in at most T*B new pages
     c = EmbeddingCache([rows] * T, D, cache_pages, cache_pages + headroom, rows_per_page=rows_per_page)
     c.write(seed=1)
+    if wb == "async":       # victims are parked in HBM and written to the store beside the next lookup's misses
+        c.set_async_writeback(headroom)
     gen = torch.Generator(device="cuda").manual_seed(5)
     batches = []
 
@@ -70,7 +72,7 @@ def run(T, rows, D, B, steps, warm, frac, rows_per_page, alpha, dist):
     written = int(c1["write"].sum())
     st = c.state()
     page_bytes = rows_per_page * D * 4
-    rec = {"cache_fraction": frac, "rows_per_page": rows_per_page, "ids": dist, "tables": T, "rows": rows, "dim": D,
+    rec = {"cache_fraction": frac, "rows_per_page": rows_per_page, "writeback": wb, "ids": dist, "tables": T, "rows": rows, "dim": D,
            "batch": B, "table_GB": T * rows * D * 4 / 1e9, "cache_GB": cache_pages * page_bytes / 1e9,
            "hit_rate_lookups": hit / max(hit + miss, 1), "pages_read_per_batch": read_pages / steps,
            "pages_written_back_per_batch": written / steps, "samples_per_s": B * steps / dt,
@@ -157,6 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=1.05)
     ap.add_argument("--fracs", default="0.5,0.25,0.125,0.0625")
+    ap.add_argument("--wb", default="async", choices=["async", "sync"],
+                    help="page-LRU policy: victims written back beside the next lookup (dlrm_cache_set_async_writeback) or inside the reclaim")
     ap.add_argument("--rpp", default="", help="rows per page, comma separated (default: 1 and the 4096-byte page)")
     ap.add_argument("--policy", default="lru", choices=["lru", "vec"],
                     help="lru: the page/row LRU cache; vec: the vector-granular policy over a log-structured store")
@@ -175,11 +179,11 @@ def main():
     rpps = [int(x) for x in a.rpp.split(",")] if a.rpp else [1, 4096 // (a.dim * 4)]
     for rpp in rpps:
         for frac in fracs:
-            rec = run(a.tables, a.rows, a.dim, a.batch, a.steps, a.warmup, frac, rpp, a.alpha, "zipf")
+            rec = run(a.tables, a.rows, a.dim, a.batch, a.steps, a.warmup, frac, rpp, a.alpha, "zipf", a.wb)
             res.append(rec)
             print(json.dumps(rec), flush=True)
     if not a.rpp:
-        rec = run(a.tables, a.rows, a.dim, a.batch, a.steps, a.warmup, 0.25, 1, a.alpha, "uniform")
+        rec = run(a.tables, a.rows, a.dim, a.batch, a.steps, a.warmup, 0.25, 1, a.alpha, "uniform", a.wb)
         res.append(rec)
         print(json.dumps(rec), flush=True)
     if a.out:
