@@ -278,11 +278,12 @@ def roofline_of(dom, gemm, traffic):
 def load_traffic(world, workload):
     """HBM bytes per operator launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) of the
     same workload ("config:global batch") on one GPU; nothing for any other run."""
-    tpath = os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        d = json.load(open(tpath))
-        if d.get("workload") == workload:
-            return d.get("per_op_bytes_per_launch", {})
+    for name in ("round3_hbm_traffic.json", "round2_hbm_traffic.json"):      # the newest pass of this workload
+        tpath = os.path.join(ROOT, "profiles", name)
+        if world == 1 and os.path.exists(tpath):
+            d = json.load(open(tpath))
+            if d.get("workload") == workload:
+                return d.get("per_op_bytes_per_launch", {})
     return {}
 
 

@@ -72,6 +72,50 @@ def _update_beside_weight_gradients(ops):
             assert torch.equal(dw, dwr) and torch.equal(db, dbr)
 
 
+def test_f16_piece_products_beside_bf16_piece_weight_gradients_equal_the_serial_run():
+    """The other direction: the victims are the kernels whose operand split uses v_cvt_pk_f16_f32 / v_fma_mix_f32 (the
+    f16x2 forward and backward-data products, with and without pre-split weights), the neighbours the bf16x3
+    weight-gradient GEMMs that disturbed the sparse update."""
+    from dlrm_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    M = 8192
+    x = torch.relu(torch.randn(M, 512, device=dev, generator=gen))
+    w = torch.randn(1024, 512, device=dev, generator=gen) / 512 ** 0.5
+    dz = torch.randn(M, 1024, device=dev, generator=gen) * (torch.rand(M, 1024, device=dev, generator=gen) > 0.5)
+    bias = torch.randn(1024, device=dev, generator=gen)
+    agg = [(torch.randn(M, 256, device=dev, generator=gen), torch.randn(M, 512, device=dev, generator=gen),
+            torch.empty(256, 512, device=dev), torch.empty(256, device=dev))]
+    wsd = torch.empty(ops.linear_backward_weight_workspace_bytes(M, 256, 512), dtype=torch.uint8, device=dev)
+    old = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode(2)
+        planes = ops.SplitWeights(w)
+
+        def victims():
+            return [ops.linear_forward(x, w, bias, True), ops.linear_backward_data(dz, w, relu_mask=x),
+                    ops.linear_forward(x, w, bias, True, w_planes=planes), ops.linear_backward_data(dz, w, w_planes=planes)]
+
+        ref = victims()
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        for rep in range(6):
+            torch.cuda.synchronize()
+            ops.set_gemm_mode(1)
+            with torch.cuda.stream(sb):
+                for _ in range(12):
+                    for gz, gx, dw, db in agg:
+                        ops.linear_backward_weight(gz, gx, dw, db, workspace=wsd)
+            ops.set_gemm_mode(2)
+            with torch.cuda.stream(sa):
+                got = victims()
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(got, ref)):
+                assert torch.equal(a, b), "repetition %d, product %d differs from the serial run" % (rep, i)
+    finally:
+        ops.set_gemm_mode(old)
+
+
 @pytest.mark.parametrize("shape", ["kaggle", "mlperf_capped"])
 def test_c_hosted_step_with_a_lagging_weight_gradient_stream_is_repeatable(shape):
     """Timing events around every weight gradient hold that stream back until it overlaps the sparse update; tables,
