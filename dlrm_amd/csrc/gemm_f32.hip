@@ -901,7 +901,9 @@ __device__ inline void f16p_interleave() {
 // compute unit).  Measured equal (the kernel does not wait for A; with all of its parts it runs at the chip's power
 // limit, 1.7 GHz in back-to-back launches: every part's cost shows up in the clock); only 2 is built outside the
 // diagnostic build.
-template <bool TAIL, bool ADMA, bool BDMA, int NI, int ABL = 0, int AST = 2>
+// TRANSPOSED_W changes no code: it puts the product into the kernel's name (false: x W^T, the forward pass; true: dz W,
+// backward-data), so that a profiler's per-kernel sums tell the two apart
+template <bool TAIL, bool ADMA, bool BDMA, int NI, int ABL = 0, int AST = 2, bool TRANSPOSED_W = false>
 __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kernel(GemmParams p) {
     constexpr int kPStage = 4096 * NI;          // bytes per B stage: h plane, l plane, 32 NI rows of 64 bytes each
     // LDS: two stages of B planes (16 KB each, shared by the four waves), then two stages of raw float32 A rows
@@ -1442,8 +1444,9 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
                  "w_planes do not belong to this layer's weight matrix");
     const int64_t k32 = ceil_div(p.K, 32) * 32;
     if (!p.a_vec || (p.K % 32 != 0 && p.lda < k32)) return DLRM_OK;
-    // DLRM_F16P_PATH (tuning aid): bit 0 = A rows, bit 1 = B planes through registers instead of global -> LDS directly
-    static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? atoi(e) & 3 : 0; }();
+    // DLRM_F16P_PATH=1 (tuning aid): both operands through registers instead of global -> LDS directly (the mixed
+    // forms were measured too, all within 5 %; the kernel keeps the switches, two forms are built)
+    static const int path = [] { const char *e = getenv("DLRM_F16P_PATH"); return e ? (atoi(e) != 0) : 0; }();
     // 128 x 256 tiles -- NI = 8, one wave per SIMD with 256 accumulator registers, half the split arithmetic per MFMA --
     // were measured slower than two 128 x 128 workgroups per compute unit on every layer of the MLPerf model at batch
     // 65536 (1024 x 1024 forward: 543 against 486 us on one box): with one wave per SIMD nothing covers a wave's
@@ -1462,8 +1465,10 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
     const bool tail = p.K % 32 != 0;
 #define DLRM_F16P_LAUNCH(A, B)                                                                         \
     do {                                                                                               \
-        if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4>), grid, block, 0, s, p);         \
-        else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4>), grid, block, 0, s, p);             \
+        if (tail && transposed) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4, 0, 2, true>), grid, block, 0, s, p);        \
+        else if (tail) hipLaunchKernelGGL((gemm_f16p_kernel<true, A, B, 4, 0, 2, false>), grid, block, 0, s, p);              \
+        else if (transposed) hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4, 0, 2, true>), grid, block, 0, s, p);        \
+        else hipLaunchKernelGGL((gemm_f16p_kernel<false, A, B, 4, 0, 2, false>), grid, block, 0, s, p);                       \
     } while (0)
 #ifdef DLRM_F16P_ABLATE
     static const int abl = [] { const char *e = getenv("DLRM_F16P_ABLATE"); return e ? atoi(e) : 0; }();
@@ -1481,12 +1486,8 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
     }
 #undef DLRM_F16P_ABL
 #endif
-    switch (path) {
-    case 0: DLRM_F16P_LAUNCH(true, true); break;
-    case 1: DLRM_F16P_LAUNCH(false, true); break;
-    case 2: DLRM_F16P_LAUNCH(true, false); break;
-    default: DLRM_F16P_LAUNCH(false, false); break;
-    }
+    if (path == 0) DLRM_F16P_LAUNCH(true, true);
+    else DLRM_F16P_LAUNCH(false, false);
 #undef DLRM_F16P_LAUNCH
     DLRM_LAUNCH_CHECK();
     *done = true;

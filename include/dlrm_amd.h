@@ -187,9 +187,14 @@ int dlrm_embbag_backward_apply(const dlrm_embbag *e, const float *d_grad, int64_
  *      sum_k |a_ik b_kj|, like a float32 fma chain) at 8/3 of the float32 matrix-pipe rate.
  *   DLRM_GEMM_F32_MFMA: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered float32 fma chain.
  *   DLRM_GEMM_F16X2: each operand is multiplied by the power of two that puts its largest magnitude just below
- *      2^14 and every element is split into two f16 pieces (h = f16(x s), l = f16(x s - h): 22 mantissa bits); the
- *      three leading cross terms run on v_mfma_f32_32x32x16_f16 with float32 accumulation and the result is scaled
- *      back.  The representation error is about one float32 ulp of each product (7.5e-8 relative rms, against a
+ *      2^14 and every element is split into two f16 pieces, h = f16(x s) and l = f16((x s - h) 2^11) (the low
+ *      piece is carried 2^11 times too large so that it stays a normal f16 number); h_a h_b goes to one float32
+ *      accumulator, h_a l_b + l_a h_b to a second one that enters the result times 2^-11, on
+ *      v_mfma_f32_32x32x16_f16, and the result is scaled back.  GUARANTEED RANGE: every element within 2^27 of its
+ *      operand's largest magnitude keeps 22 mantissa bits whatever else the tensor holds; an element further down
+ *      has an absolute error of at most 2^-48 of that largest magnitude (float32, BF16X3 and F32_MFMA have no such
+ *      floor: operands spanning more than eight decades want one of those).  Within that range the
+ *      representation error is about one float32 ulp of each product (7.5e-8 relative rms, against a
  *      float64 product; the float32 accumulation of ANY of the modes, this one included, contributes 2e-7 to 4e-7 at
  *      reduction lengths of 512 to 65536), at half the matrix work of BF16X3: 1.3 to 1.6 times faster on the
  *      65536-row layers.  It needs max |x| of both operands before the kernel starts: handed in through the

@@ -22,6 +22,9 @@ timeout -k 10 400 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 timeout -k 10 200 python3 bench.py --global-batch 8192 --no-cpu-baseline > $OUT/b8192_bench_line.json 2> $OUT/b8192.err
 timeout -k 10 200 python3 bench.py --config kaggle --no-cpu-baseline > $OUT/kaggle_bench_line.json 2> $OUT/kaggle.err
 timeout -k 10 300 python3 bench.py --dist zipf --no-cpu-baseline > $OUT/zipf_bench_line.json 2> $OUT/zipf.err
+timeout -k 10 200 python3 bench.py --global-batch 8192 --force-exchange --no-cpu-baseline > $OUT/b8192_exchange_bench_line.json 2> $OUT/b8192x.err
+timeout -k 10 200 python3 bench.py --config kaggle --graph --no-cpu-baseline > $OUT/kaggle_graph_bench_line.json 2> $OUT/kaggle_graph.err
+timeout -k 10 300 python3 -u tools/gemm_modes.py 65536 $OUT/gemm_modes.json > $OUT/gemm_modes.log 2>&1
 echo "== profiles"
 bash tools/gpu_profiles.sh $TAG bench b8192 kaggle mfma
 echo "== sweeps"

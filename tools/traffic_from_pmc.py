@@ -20,6 +20,10 @@ import sys
 
 # kernel-name fragment -> (operator, counts as one operator launch?)
 RULES = [
+    ("gemm_f16p_kernel<true, true, true, 4, 0, 2, false>", "linear_forward", True),     # (… TAIL, paths, NI, -, -, W transposed)
+    ("gemm_f16p_kernel<false, true, true, 4, 0, 2, false>", "linear_forward", True),
+    ("gemm_f16p_kernel<true, true, true, 4, 0, 2, true>", "linear_backward_data", True),
+    ("gemm_f16p_kernel<false, true, true, 4, 0, 2, true>", "linear_backward_data", True),
     ("gemm_split_kernel<true, true", "linear_forward", True),
     ("gemm_f32_kernel<true, true", "linear_forward", True),
     ("gemm_split_kernel<true, false", "linear_backward_data", True),
@@ -28,6 +32,8 @@ RULES = [
     ("gemm_f32_kernel<false, false", "linear_backward_weight", True),
     ("reduce_slabs_kernel", "linear_backward_weight", False),
     ("absmax_kernel", "operand_maxima", True),
+    ("absmax_many_kernel", "operand_maxima", True),
+    ("split_weights_kernel", "operand_maxima", False),
     ("skinny_k_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_bwd_data_kernel", "linear_backward_data_skinny", True),
@@ -36,6 +42,9 @@ RULES = [
     ("embbag_fwd", "embbag_forward", True),
     ("expand_pairs_kernel", "embbag_backward_prepare", True),    # ids only: pairs + sort, beside the forward pass
     ("rocprim", "embbag_backward_prepare", False),
+    ("digit_hist_kernel", "embbag_backward_prepare", False),
+    ("digit_offsets_kernel", "embbag_backward_prepare", False),
+    ("digit_scatter_kernel", "embbag_backward_prepare", False),
     ("sparse_update_kernel", "embbag_backward_update", True),
     ("combine_runs_kernel", "embbag_backward_update", False),
     ("interact_dot_fwd", "interact_dot_forward", True),
