@@ -391,9 +391,21 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
 static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, bool train, hipStream_t main) {
     hipStream_t emb = m->s_emb ? m->s_emb : main;
     if (int rc = begin_pass_maxima(m, main)) return rc;
-    if (train && m->cfg.presort) {
-        hipStream_t prep = m->s_prep ? m->s_prep : main;
-        if (int rc = wait_for(m, prep, main)) return rc;
+    // The sort of the batch's ids (first half of the sparse update) runs on its own stream from HERE on the device --
+    // behind everything the main stream holds at this point -- but its dozen launches are handed to the driver only
+    // after the main stream's first kernels: at small batches the host would otherwise keep the main stream waiting
+    // for as long as it takes to enqueue them.
+    hipStream_t prep = m->s_prep ? m->s_prep : main;
+    hipEvent_t prep_from = nullptr;
+    bool prep_todo = train && m->cfg.presort;
+    if (prep_todo && prep != main) {
+        prep_from = m->events[m->next_event++ % m->events.size()];
+        DLRM_HIP(hipEventRecord(prep_from, main));
+    }
+    auto launch_prepare = [&]() -> int {
+        if (!prep_todo) return DLRM_OK;
+        prep_todo = false;
+        if (prep_from) DLRM_HIP(hipStreamWaitEvent(prep, prep_from, 0));
         if (m->Tl) {
             dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
             if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
@@ -406,7 +418,10 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
                                [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse_rw, m->ws_sparse_rw_bytes, prep); }))
                 return rc;
         }
-    }
+        return DLRM_OK;
+    };
+    if (prep == main)      // (no stream of its own: program order is device order)
+        if (int rc = launch_prepare()) return rc;
     if (!m->gather) {
         if (int rc = wait_for(m, emb, main)) return rc;   // earlier readers of feat and the input copies are done
         if (int rc = emb_forward(m, idx, off, n_idx, emb)) return rc;
@@ -429,7 +444,9 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
                                                        train ? m->feat : nullptr, out_max, main);
             }))
             return rc;
+        if (int rc = launch_prepare()) return rc;
     } else {
+        if (int rc = launch_prepare()) return rc;
         if (int rc = wait_for(m, main, emb)) return rc;
         if (m->dot)
             if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
