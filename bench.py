@@ -174,10 +174,12 @@ def install_timers(ops, model_ref):
 KERNEL_OF = {
     "linear_forward": "%s, operands RC,RC (x W^T + b, ReLU)",
     "linear_backward_data": "%s, operands RC,RS (dz W, ReLU mask)",
-    "linear_backward_weight": "%s, operands RS,RS, split-batch + reduce_slabs + colsum (dz^T x)",
+    "linear_backward_weight": "%s, operands RS,RS, split-batch + colsum (dz^T x); partial sums of a stack's layers added by one "
+                              "reduce_slabs_many launch (its time is included)",
     "embbag_forward": "embbag_fwd_group_kernel",
     "embbag_backward_update": "sparse_update_kernel + combine_runs_kernel (segmented reduction + fused optimizer)",
-    "embbag_backward_prepare": "expand_pairs + rocprim radix sort (ids only; overlapped with the forward pass)",
+    "embbag_backward_prepare": "expand_pairs + the library's radix sort, digit_hist / digit_offsets / digit_scatter (ids only; "
+                               "overlapped with the forward pass)",
     "interact_dot_forward": "interact_dot_fwd_kernel (interact_dot_fwd_gather_kernel: reads the table rows itself when every "
                             "bag holds one id)",
     "interact_dot_backward": "interact_dot_bwd_kernel",
@@ -247,6 +249,12 @@ def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gathe
 
 def kernel_rows(timing, work, steps, gemm_name, gemm_peak):
     """timing: {class: (ms summed, launches)} over `steps` steps -> the `kernels` rows of the bench line."""
+    timing = dict(timing)
+    red = timing.pop("linear_backward_weight_reduce", None)
+    if red and "linear_backward_weight" in timing:
+        # the stacks' reductions of the partial sums are part of the weight gradients' cost (their launches keep the count)
+        ms, n = timing["linear_backward_weight"]
+        timing["linear_backward_weight"] = (ms + red[0], n)
     rows = []
     for name, (ms, launches) in timing.items():
         wk, kind = work.get(name, (0.0, "hbm"))
@@ -364,8 +372,10 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     for i in range(args.warmup - n_probe, args.warmup):
         step(i)
     probe = model.collect_timing()
-    timed_cls = [k for k, _ in sorted(probe.items(), key=lambda kv: -kv[1][0]) if k != "embbag_backward_prepare"][:1] \
-        or ["linear_backward_data"]
+    timed_cls = [k for k, _ in sorted(probe.items(), key=lambda kv: -kv[1][0])
+                 if k not in ("embbag_backward_prepare", "linear_backward_weight_reduce")][:1] or ["linear_backward_data"]
+    if timed_cls == ["linear_backward_weight"]:
+        timed_cls.append("linear_backward_weight_reduce")      # (part of that class's cost: kernel_rows adds it in)
     model.enable_timing([] if args.graph else timed_cls, 16 * args.steps)
     if args.graph:
         for i in range(n_batches):      # capture every resident batch before the timed region

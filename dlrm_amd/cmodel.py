@@ -162,7 +162,7 @@ class CModel:
     TIME_CLASSES = ("linear_forward", "linear_backward_data", "linear_backward_weight", "linear_forward_skinny",
                     "linear_backward_data_skinny", "linear_backward_weight_skinny", "embbag_forward",
                     "embbag_backward_prepare", "embbag_backward_update", "interact_dot_forward", "interact_dot_backward",
-                    "comm_forward_exchange", "comm_backward_exchange", "comm_all_reduce")
+                    "comm_forward_exchange", "comm_backward_exchange", "comm_all_reduce", "linear_backward_weight_reduce")
 
     def enable_timing(self, classes, max_records):
         """classes: names out of TIME_CLASSES (or "all"); [] switches the timing off."""

@@ -105,6 +105,25 @@ struct AbsmaxItem {
 };
 int absmax_many(const AbsmaxItem *items, int n, hipStream_t s);
 
+// Weight gradients whose partial sums are added up LATER, several layers by one launch (gemm_f32.hip): the products of
+// a stack's layers leave their slabs in workspaces of their own, reduce_slabs_many adds all of them in the fixed order
+// dlrm_linear_backward_weight uses (same results, bit for bit).
+struct SlabSum {          // out[r * ld_out + c] = sum_s slabs[s * stride + r * cols + c]
+    const float *slabs;
+    int64_t stride;
+    int rows, cols;
+    float *out;
+    int64_t ld_out;
+};
+struct SlabReduce {       // what one layer leaves to do: its weight gradient and (has_b) its bias gradient; splits 0 = nothing
+    SlabSum w, b;
+    int splits;
+    int has_b;
+};
+int linear_backward_weight_deferred(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes, SlabReduce *pending,
+                                    dlrm_stream_t stream);
+int reduce_slabs_many(const SlabReduce *items, int n, hipStream_t s);
+
 // Stable sort of (key, value) pairs by the low `bits` bits of the key (pair_sort.hip: least-significant-digit radix sort,
 // digits of up to 10 bits).  The pairs start in (keys_a, vals_a) and end there when pair_sort_passes(bits) is even, in
 // (keys_b, vals_b) when it is odd; both pairs of buffers are overwritten.  tmp: pair_sort_tmp_bytes(n) bytes.

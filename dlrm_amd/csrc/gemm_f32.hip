@@ -1178,20 +1178,9 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitJobs jobs) {
 // flight, and the four partial sums meet in LDS in a fixed order (deterministic).  One launch serves two
 // such problems with the same number of slabs (a weight gradient and its bias gradient): workgroups
 // [0, blocks_a) take the first, the rest the second.
-struct SlabSum {
-    const float *slabs;
-    int64_t stride;
-    int rows, cols;
-    float *out;
-    int64_t ld_out;
-};
-
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(SlabSum pa, SlabSum pb, int splits, unsigned blocks_a) {
+// (struct SlabSum: common.h)
+__device__ inline void reduce_slabs_body(const SlabSum &p, int splits, unsigned bid, unsigned nblk) {
     __shared__ float part[4][64];
-    const bool second = blockIdx.x >= blocks_a;
-    const SlabSum p = second ? pb : pa;
-    const unsigned bid = second ? blockIdx.x - blocks_a : blockIdx.x;
-    const unsigned nblk = second ? gridDim.x - blocks_a : blocks_a;
     const float *__restrict__ slabs = p.slabs;
     const int64_t n = (int64_t)p.rows * p.cols;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1220,14 +1209,70 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(SlabSum pa, SlabSum p
     }
 }
 
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(SlabSum pa, SlabSum pb, int splits, unsigned blocks_a) {
+    const bool second = blockIdx.x >= blocks_a;
+    reduce_slabs_body(second ? pb : pa, splits, second ? blockIdx.x - blocks_a : blockIdx.x,
+                      second ? gridDim.x - blocks_a : blocks_a);
+}
+
+// the same for up to kReduceJobs problems with their own numbers of slabs: workgroups [first[j], first[j+1]) take job j
+constexpr int kReduceJobs = 24;
+struct ReduceJobs {
+    SlabSum p[kReduceJobs];
+    int splits[kReduceJobs];
+    unsigned first[kReduceJobs + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_many_kernel(ReduceJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.first[j + 1]) j++;
+    reduce_slabs_body(jobs.p[j], jobs.splits[j], blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j]);
+}
+
+static unsigned reduce_blocks(int64_t n) { return (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096); }
+
+int reduce_slabs_many(const SlabReduce *items, int n, hipStream_t s) {
+    DLRM_REQUIRE(n >= 0 && (items != nullptr || n == 0), "bad arguments");
+    ReduceJobs jobs{};
+    auto flush = [&]() -> int {
+        if (jobs.n == 0) return DLRM_OK;
+        hipLaunchKernelGGL(reduce_slabs_many_kernel, dim3(jobs.first[jobs.n]), dim3(256), 0, s, jobs);
+        DLRM_LAUNCH_CHECK();
+        jobs.n = 0;
+        return DLRM_OK;
+    };
+    auto add = [&](const SlabSum &p, int splits) -> int {
+        if (jobs.n == kReduceJobs)
+            if (int rc = flush()) return rc;
+        if (jobs.n == 0) jobs.first[0] = 0;
+        jobs.p[jobs.n] = p;
+        jobs.splits[jobs.n] = splits;
+        jobs.first[jobs.n + 1] = jobs.first[jobs.n] + reduce_blocks((int64_t)p.rows * p.cols);
+        jobs.n++;
+        return DLRM_OK;
+    };
+    for (int i = 0; i < n; i++) {
+        if (items[i].splits <= 0) continue;
+        if (int rc = add(items[i].w, items[i].splits)) return rc;
+        if (items[i].has_b)
+            if (int rc = add(items[i].b, items[i].splits)) return rc;
+    }
+    return flush();
+}
+
 // dW (and db, if wanted) from their partial sums, one launch
+// (pending: the reduction is not launched but written down for reduce_slabs_many)
 static int launch_reduce(const float *slabs, int64_t stride, int N, int K, float *dw, int64_t dw_ld, const float *db_slabs,
-                         float *db, int splits, hipStream_t s) {
+                         float *db, int splits, hipStream_t s, SlabReduce *pending = nullptr) {
     const int64_t n = (int64_t)N * K;
-    const unsigned blocks_a = (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096);
+    const unsigned blocks_a = reduce_blocks(n);
     const unsigned blocks_b = db ? (unsigned)ceil_div(N, 64) : 0u;
     SlabSum a{slabs, stride, N, K, dw, dw_ld};
     SlabSum b{db_slabs, (int64_t)N, 1, N, db, (int64_t)N};
+    if (pending) {
+        pending->w = a; pending->b = b; pending->splits = splits; pending->has_b = db != nullptr;
+        return DLRM_OK;
+    }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, s, a, b, splits, blocks_a);
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
@@ -1623,7 +1668,8 @@ extern "C" int dlrm_linear_backward_weight_workspace_bytes(int64_t M, int32_t N,
 }
 
 static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
-                                dlrm_stream_t stream) {
+                                dlrm_stream_t stream, SlabReduce *pending = nullptr) {
+    if (pending) pending->splits = 0;
     DLRM_REQUIRE(l != nullptr, "linear_bwd descriptor is NULL");
     DLRM_REQUIRE(l->M >= 1 && l->N >= 1 && l->K >= 1, "bad shape");
     DLRM_REQUIRE(l->M < (1ll << 31), "M too large");
@@ -1649,7 +1695,7 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
                                   : gemv_backward_weight(l->d_dz, l->dz_ld, l->d_x, l->x_ld, slabs, dbp, (int)l->M, l->K, cap,
                                                          &chunks, s);
         if (rc) return rc;
-        return launch_reduce(slabs, (int64_t)l->N * l->K, l->N, l->K, l->d_dw, l->dw_ld, dbp, l->d_db, chunks, s);
+        return launch_reduce(slabs, (int64_t)l->N * l->K, l->N, l->K, l->d_dw, l->dw_ld, dbp, l->d_db, chunks, s, pending);
     }
     GemmParams p{};
     p.A = l->d_dz; p.lda = l->dz_ld; p.B = l->d_x; p.ldb = l->x_ld;
@@ -1668,7 +1714,8 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
         p.colsum = l->d_db ? db_partial : nullptr;
         const int real_splits = (int)ceil_div(l->M, p.k_per_split);
         if (int rc = launch_gemm<false, false>(p, real_splits, ts, l->gemm_mode, s)) return rc;
-        if (int rc = launch_reduce(slabs, p.slab_stride, l->N, l->K, l->d_dw, l->dw_ld, db_partial, l->d_db, real_splits, s))
+        if (int rc = launch_reduce(slabs, p.slab_stride, l->N, l->K, l->d_dw, l->dw_ld, db_partial, l->d_db, real_splits, s,
+                                   pending))
             return rc;
     }
     return DLRM_OK;
@@ -1677,6 +1724,12 @@ static int backward_weight_impl(const dlrm_linear_bwd *l, void *d_workspace, siz
 extern "C" int dlrm_linear_backward_weight(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
                                            dlrm_stream_t stream) {
     return backward_weight_impl(l, d_workspace, workspace_bytes, stream);
+}
+
+int dlrm::linear_backward_weight_deferred(const dlrm_linear_bwd *l, void *d_workspace, size_t workspace_bytes,
+                                          SlabReduce *pending, dlrm_stream_t stream) {
+    DLRM_REQUIRE(pending != nullptr, "pending is NULL");
+    return backward_weight_impl(l, d_workspace, workspace_bytes, stream, pending);
 }
 
 // ---- the same product with the partial-sum slabs in a buffer that is part of the loaded code object ----

@@ -35,6 +35,7 @@ struct Layer {
     int64_t w_off, w_ld, b_off;   // offsets into the flat parameter / gradient buffers
     int s_x = -1, s_w = -1, s_dz = -1;   // f16x2 evaluation: slots of max |input|, max |W|, max |dz| in dlrm_model::amax
     dlrm_weight_planes planes{};         // f16x2 evaluation: the matrix cut into its f16 pieces once per pass (d_planes NULL: not kept)
+    size_t ws_off = 0, ws_bytes = 0;     // this layer's share of the weight-gradient workspace (partial sums wait there for the stack's one reduction)
 };
 
 struct Act {   // a [B, n] activation: pointer + leading dimension
@@ -241,7 +242,9 @@ static int linear_dgrad(dlrm_model *m, const Layer &l, int64_t col0, int K, cons
 }
 
 // (the maxima of dz and x are in their slots by now: stack_backward sees to dz, the forward pass to x)
-static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, hipStream_t s) {
+// pending: the layer's partial sums stay in its workspace, to be added up by the stack's one reduce_slabs_many launch
+static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t dz_ld, const float *x, int64_t x_ld, hipStream_t s,
+                        SlabReduce *pending) {
     dlrm_linear_bwd d{};
     d.M = m->B; d.N = l.N; d.K = l.K; d.d_dz = dz; d.dz_ld = dz_ld; d.d_x = x; d.x_ld = x_ld;
     d.d_dw = m->grads + l.w_off; d.dw_ld = l.w_ld; d.d_db = m->grads + l.b_off; d.gemm_mode = m->cfg.gemm_mode;
@@ -251,7 +254,15 @@ static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t 
         d.d_x_absmax = m->amax_valid[l.s_x] ? m->amax + l.s_x : nullptr;
     }
     return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY : DLRM_TIME_LINEAR_BACKWARD_WEIGHT, s,
-                 [&] { return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s); });
+                 [&] {
+                     // DLRM_WGRAD_DEFER=0 (A/B aid): every layer adds its partial sums up by itself
+                     static const bool defer = [] { const char *e = getenv("DLRM_WGRAD_DEFER"); return !(e && e[0] == '0'); }();
+                     if (!defer) {
+                         pending->splits = 0;
+                         return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s);   // (one area for all: as before)
+                     }
+                     return linear_backward_weight_deferred(&d, static_cast<char *>(m->ws_dense) + l.ws_off, l.ws_bytes, pending, s);
+                 });
 }
 
 // Backward of one MLP stack (MLPStack.backward): the weight gradient of every layer goes to the wgrad stream
@@ -261,6 +272,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
                           float *dx_first, int64_t dx_first_ld, hipStream_t s) {
     const int n = (int)st.size();
     hipStream_t sw = m->s_wgrad ? m->s_wgrad : s;
+    std::vector<SlabReduce> pending((size_t)n);
     for (int i = n - 1; i >= 0; i--) {
         const float *dz = i == n - 1 ? dz_last : dz_bufs[i].p;
         const int64_t dz_ld = i == n - 1 ? dz_last_ld : dz_bufs[i].ld;
@@ -269,7 +281,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
         if (big_layer(m, st[i]))                          // (a dz that no GEMM wrote: measured here, ahead of both readers)
             if (int rc = need_max(m, st[i].s_dz, dz, st[i].N, dz_ld, m->B, s)) return rc;
         if (int rc = wait_for(m, sw, s)) return rc;      // dz of this layer is complete
-        if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw)) return rc;
+        if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw, &pending[(size_t)i])) return rc;
         if (i > 0) {
             if (int rc = linear_dgrad(m, st[i], 0, st[i].K, dz, dz_ld, dz_bufs[i - 1].p, dz_bufs[i - 1].ld, acts[i - 1].p,
                                       acts[i - 1].ld, s, big_layer(m, st[i - 1]) ? st[i - 1].s_dz : -1))
@@ -278,7 +290,9 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
             if (int rc = linear_dgrad(m, st[0], 0, st[0].K, dz, dz_ld, dx_first, dx_first_ld, nullptr, 0, s)) return rc;
         }
     }
-    return DLRM_OK;
+    // the partial sums of all layers of the stack, one launch (a reduction per layer is a string of 5-50 us launches
+    // on the weight-gradient stream: 0.1 ms of a 0.9 ms step at a local batch of 8192)
+    return timed(m, DLRM_TIME_LINEAR_BACKWARD_WEIGHT_REDUCE, sw, [&] { return reduce_slabs_many(pending.data(), n, sw); });
 }
 
 static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, hipStream_t s) {
@@ -687,12 +701,15 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     if ((rc = dalloc(m, &m->loss, 1))) return fail(rc);
 
     // ---- workspaces: the largest any layer / any batch of the configured shape needs
+    // (every layer its own share: the partial sums of a stack's layers are added up together, behind the last of them)
     size_t need = 0;
-    for (const auto *st : {&m->bot, &m->topl})
-        for (const Layer &l : *st) {
+    for (auto *st : {&m->bot, &m->topl})
+        for (Layer &l : *st) {
             size_t b = 0;
             if ((rc = dlrm_linear_backward_weight_workspace_bytes(m->B, l.N, l.K, &b))) return fail(rc);
-            if (b > need) need = b;
+            l.ws_off = need;
+            l.ws_bytes = b;
+            need += (b + 255) / 256 * 256;
         }
     m->ws_dense_bytes = need;
     {

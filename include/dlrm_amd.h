@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1016
+#define DLRM_ABI_VERSION 1017
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -892,6 +892,8 @@ enum {
     DLRM_TIME_INTERACT_DOT_FORWARD, DLRM_TIME_INTERACT_DOT_BACKWARD,
     /* the collectives of a sharded step (time on their stream, waiting for the slowest peer included) */
     DLRM_TIME_COMM_FORWARD_EXCHANGE, DLRM_TIME_COMM_BACKWARD_EXCHANGE, DLRM_TIME_COMM_ALL_REDUCE,
+    /* the one launch per MLP stack that adds up the partial sums of all its layers' weight and bias gradients */
+    DLRM_TIME_LINEAR_BACKWARD_WEIGHT_REDUCE,
     DLRM_TIME_NUM_CLASSES
 };
 int dlrm_model_enable_timing(dlrm_model *m, uint32_t class_mask, int32_t max_records);
