@@ -1111,6 +1111,268 @@ __global__ __launch_bounds__(kGemmThreads, NI == 8 ? 1 : 2) void gemm_f16p_kerne
     }
 }
 
+// ---- gemm_f16p_kernel on v_mfma_f32_16x16x32_f16 ----------------------------------------------------------------
+// Same product, same operands, same pipeline (both operands global -> LDS directly, two stages each, A rows wave
+// private, one barrier per step), the matrix work as 48 MFMAs of 16 x 16 x 32 per step instead of 24 of 32 x 32 x 16:
+// an accumulator element is read and written once per 32 multiply-adds instead of once per 16, and on operands that
+// toggle the multipliers the part sustains 12 % more of them (tools/f16p_shape_bench.hip: 0.65 against 0.58 of
+// 2.5 PFLOP/s) -- the kernel runs at the power limit, so that is time.  What changes is who holds what:
+//   A: lane (r = lane & 15, g = lane >> 4) owns reduction elements 8g .. 8g+7 of rows r and 16 + r of the wave's 32: the
+//      32 bytes at chunks 2g, 2g+1 of a row's 128; chunk c of row r sits at position c ^ aq_sw(r) of the row's image
+//   B: lane (n, g) reads chunk g of column n's 64 bytes for each of the 8 column blocks; chunk c of row n sits at
+//      position c ^ (0, 2, 3, 1)[(n >> 2) & 3]
+// (both conflict-free for the four 16-lane groups a ds_read_b128 is served in), and the 16 x 16 result blocks: lane
+// (n, g) holds column n, rows 4g .. 4g+3.
+__device__ inline int bq_swz(int n) { return (0x1320 >> (4 * ((n >> 2) & 3))) & 3; }
+__device__ inline int aq_swz(int r) { const int x = (r >> 1) & 7; return 6 * ((x >> 2) & 1) + (x & 1); }
+
+// r[2m], r[2m+1]: the lane's 8 elements of row block m; elements at or beyond k_left (counted from the lane's first)
+// are zeroed in a TAIL launch
+template <bool TAIL>
+__device__ inline void f16q_split(const f32x4 (&r)[4], float scale, int k_left, bf16x8 (&f)[2][2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            f32x4 x = r[2 * m + q];
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) x[e] = (4 * q + e) < k_left ? x[e] : 0.f;
+            }
+            split2_pair(f32x2{x[0], x[1]}, scale, h[2 * q], l[2 * q]);
+            split2_pair(f32x2{x[2], x[3]}, scale, h[2 * q + 1], l[2 * q + 1]);
+        }
+        f[m][0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+        f[m][1] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    }
+}
+
+// a step's 48 MFMAs: the raw A rows and the fragments of the first two column blocks early, the fragments of column
+// block cb + 2 behind the MFMAs of block cb, the next step's split spread behind all of them
+template <int I>
+__device__ inline void f16q_interleave() {
+    constexpr int kMfma = 48, kValu = 84;
+    if constexpr (I == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if constexpr (I < kMfma) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (I % 6 == 5 && I / 6 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (kValu * (I + 1)) / kMfma - (kValu * I) / kMfma, 0);
+        f16q_interleave<I + 1>();
+    }
+}
+
+// the epilogue of store_output for 32 rows x 64 columns held as 2 x 4 blocks of 16 x 16 (one wave per 32 rows)
+__device__ inline void store_output16(const GemmParams &p, const f32x4 (&acc)[2][4], float *ct_all, int m0, int n0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int CT_LD = 64 + 4, LPR = 16, RPI = 4;
+    float *ct = ct_all + wave * (32 * CT_LD);
+    const int cn = n0 + (lane % LPR) * 4;
+    const bool c_vec = (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) && (p.ldc % 4 == 0) &&
+                       (p.mask == nullptr || ((reinterpret_cast<uintptr_t>(p.mask) % 16 == 0) && (p.mask_ld % 4 == 0)));
+    float vmax = 0.f;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+        if (cn < p.N) bv.x = p.bias[cn];
+        if (cn + 1 < p.N) bv.y = p.bias[cn + 1];
+        if (cn + 2 < p.N) bv.z = p.bias[cn + 2];
+        if (cn + 3 < p.N) bv.w = p.bias[cn + 3];
+    }
+    float4 mk[32 / RPI];
+    const bool mask_vec = p.mask != nullptr && c_vec && cn + 3 < p.N;
+    if (mask_vec) {
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int m = m0 + wave * 32 + it * RPI + (lane / LPR);
+            mk[it] = *reinterpret_cast<const float4 *>(p.mask + (int64_t)(m < p.M ? m : p.M - 1) * p.mask_ld + cn);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ct[(16 * m + 4 * (lane >> 4) + r) * CT_LD + 16 * cb + (lane & 15)] = acc[m][cb][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; it++) {
+        const int row = it * RPI + (lane / LPR);
+        const int m = m0 + wave * 32 + row;
+        float4 v = *reinterpret_cast<const float4 *>(ct + row * CT_LD + (lane % LPR) * 4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (m >= p.M || cn >= p.N) continue;
+        float *dst = p.C + (int64_t)m * p.ldc + cn;
+        if (c_vec && cn + 3 < p.N) {
+            if (mask_vec) {
+                const float4 k = mk[it];
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+                v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4 *>(dst) = v;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (cn + q < p.N) {
+                    float x = e[q];
+                    if (p.mask) x = p.mask[(int64_t)m * p.mask_ld + cn + q] > 0.f ? x : 0.f;
+                    dst[q] = x;
+                    vmax = fmaxf(vmax, fabsf(x));
+                }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (p.c_max != nullptr) fold_absmax(vmax, p.c_max);
+}
+
+template <bool TAIL, bool TRANSPOSED_W>      // (TRANSPOSED_W: part of the name only, as in gemm_f16p_kernel)
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16q_kernel(GemmParams p) {
+    constexpr int kPStage = 16384, kAStage = 16384, kAOff = 2 * kPStage;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPStage + 2 * kAStage];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const float scale_a = split2_scale(__float_as_uint(*p.a_max));
+    const float scale_b = split2_scale(__float_as_uint(*p.b_max));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int nwg = p.gx * p.gy;
+    const int lin = blockIdx.x, xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int bx = tile % p.gx, by = tile / p.gx;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int steps = (p.K + 31) / 32;
+
+    // requests: as in gemm_f16p_kernel, with this kernel's swizzles applied on the global side
+    const float *a_origin = p.A + (int64_t)m0 * p.lda;
+    unsigned a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int pr = lane >> 3, pc = lane & 7;
+        const int row = m0 + 32 * wave + 8 * j + pr;
+        const int rowc = row < p.M ? row : p.M - 1;
+        a_off[j] = (unsigned)((rowc - m0) * (int)p.lda * 4 + 16 * (pc ^ aq_swz(8 * j + pr)));
+    }
+    const int a_lds = kAOff + uwave * 4096;
+    int a_rd[2][2];       // [row block][first / second chunk] of this lane inside the wave's A image
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) a_rd[m][q] = (16 * m + l15) * 128 + 16 * ((2 * g + q) ^ aq_swz(16 * m + l15));
+    const unsigned char *b_origin = (uwave >> 1 ? p.bp_l : p.bp_h) + ((int64_t)n0 + 64 * (uwave & 1)) * 64;
+    const unsigned b_off = (unsigned)((lane >> 2) * 64 + 16 * ((lane & 3) ^ bq_swz(lane >> 2)));
+    const int b_lds = (uwave >> 1) * 8192 + (uwave & 1) * 4096;
+    const int rd = l15 * 64 + 16 * (g ^ bq_swz(l15));        // + 1024 per column block, + 8192: the l plane
+
+    f32x4 hi[2][8], lo[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { hi[m][cb][r] = 0.f; lo[m][cb][r] = 0.f; }
+
+    auto dma_a = [&](int t, int stage) {
+        const int tc = t < steps ? t : steps - 1;     // (surplus requests re-read the last step)
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_origin + 32 * tc), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + a_lds + stage * kAStage + 1024 * j), 16, (int)a_off[j], 0, 0, 0);
+    };
+    auto dma_b = [&](int t, int stage) {
+        const int tc = t < steps ? t : steps - 1;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(b_origin + tc * p.bp_ld), 0, 0xffffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + b_lds + stage * kPStage + 1024 * j), 16, (int)(b_off + 1024u * j), 0, 0, 0);
+    };
+    auto read_a = [&](int stage, f32x4 (&r)[4]) {
+        const unsigned char *base = smem + a_lds + stage * kAStage;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) r[2 * m + q] = *reinterpret_cast<const f32x4 *>(base + a_rd[m][q]);
+    };
+    auto mfma_step = [&](const unsigned char *stage, const bf16x8 (&af)[2][2]) {
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, af[0][0]), al0 = __builtin_bit_cast(f16x8, af[0][1]);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, af[1][0]), al1 = __builtin_bit_cast(f16x8, af[1][1]);
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) {
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(stage + rd + 1024 * cb);
+            const f16x8 bl = *reinterpret_cast<const f16x8 *>(stage + 8192 + rd + 1024 * cb);
+            f32x4 c = lo[0][cb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c, 0, 0, 0);
+            lo[0][cb] = c;
+            hi[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, hi[0][cb], 0, 0, 0);
+            c = lo[1][cb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c, 0, 0, 0);
+            lo[1][cb] = c;
+            hi[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, hi[1][cb], 0, 0, 0);
+        }
+    };
+
+    bf16x8 fa[2][2], fb[2][2];
+    // step t (parity par): as in gemm_f16p_kernel -- MFMAs on (B stage par, f_c); the raw A of step t+1 (A stage par^1)
+    // is read and split into f_n; B of step t+1 travels to B stage par^1, A of step t+2 to A stage par
+    auto step = [&](int t, int par, bf16x8 (&f_c)[2][2], bf16x8 (&f_n)[2][2]) {
+        dma_b(t + 1, par ^ 1);
+        dma_a(t + 2, par);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);          // the A rows of step t+1 have landed (this step's 8 requests may fly)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 raw[4];
+        read_a(par ^ 1, raw);
+        f16q_split<TAIL>(raw, scale_a, p.K - 32 * (t + 1) - 8 * g, f_n);
+        mfma_step(smem + par * kPStage, f_c);
+        f16q_interleave<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F74);              // this wave's pieces of the next B stage have landed
+        __syncthreads();
+    };
+    dma_a(0, 0);
+    dma_b(0, 0);
+    dma_a(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F74);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x4 raw[4];
+        read_a(0, raw);
+        f16q_split<TAIL>(raw, scale_a, p.K - 8 * g, fa);
+    }
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < steps; t += 2) {       // (pairs of steps without a branch, the odd last one behind them)
+        step(t, 0, fa, fb);
+        step(t + 1, 1, fb, fa);
+    }
+    if (t < steps) step(t, 0, fa, fb);
+
+    const float inv_a = 1.0f / scale_a, inv_b = 1.0f / scale_b;
+    float *fsm = reinterpret_cast<float *>(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // (surplus A requests must not land in the epilogue's staging area)
+    __syncthreads();
+#pragma unroll
+    for (int hn = 0; hn < 2; hn++) {         // 64 columns at a time: mixed terms in, operand scales out, then the usual epilogue
+        f32x4 o[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    o[m][cb][r] = (__builtin_fmaf(lo[m][4 * hn + cb][r], kSplit2LowInv, hi[m][4 * hn + cb][r]) * inv_a) * inv_b;
+        store_output16(p, o, fsm, m0, n0 + 64 * hn);
+    }
+}
+
 // ---- the planes gemm_f16p_kernel reads: for a weight matrix W [N,K], its f16 pieces (times the scale of max |W|) as
 // [K rounded up to 32, in steps of 32][N rounded up to 256][32] (forward: reduction over K) and, transposed, [N rounded
 // up to 32, in steps of 32][K rounded up to 256][32] (backward-data: reduction over N), zero in the padding.  Step-major:
@@ -1531,7 +1793,14 @@ static int launch_f16p(GemmParams p, const dlrm_weight_planes *wp, bool transpos
     }
 #undef DLRM_F16P_ABL
 #endif
-    if (path == 0) DLRM_F16P_LAUNCH(true, true);
+    // DLRM_F16P_SHAPE=32: the 32 x 32 x 16 kernel (A/B aid); default: the 16 x 16 x 32 one
+    static const int shape = [] { const char *e = getenv("DLRM_F16P_SHAPE"); return e ? atoi(e) : 16; }();
+    if (shape == 16 && path == 0) {
+        if (tail && transposed) hipLaunchKernelGGL((gemm_f16q_kernel<true, true>), grid, block, 0, s, p);
+        else if (tail) hipLaunchKernelGGL((gemm_f16q_kernel<true, false>), grid, block, 0, s, p);
+        else if (transposed) hipLaunchKernelGGL((gemm_f16q_kernel<false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm_f16q_kernel<false, false>), grid, block, 0, s, p);
+    } else if (path == 0) DLRM_F16P_LAUNCH(true, true);
     else DLRM_F16P_LAUNCH(false, false);
 #undef DLRM_F16P_LAUNCH
     DLRM_LAUNCH_CHECK();
