@@ -47,7 +47,8 @@ GEMM_CHOICES = {
     "bf16x3": (2, "gemm_split_kernel<3 bf16 pieces>", BF16X3_PEAK, 6.0,
                "float32 product = 6 bf16 MFMA terms: peak = 2500 TFLOP/s bf16 dense / 6",
                "float32 in/out; products as 6 bf16 MFMA terms of 3-way bf16 splits, f32 accumulate"),
-    "f16x2": (3, "gemm_f16p_kernel (weights pre-split; weight gradient: gemm_split_kernel<2 f16 pieces>)", F16X2_PEAK, 3.0,
+    "f16x2": (3, "gemm_f16q_kernel (v_mfma_f32_16x16x32_f16, weights pre-split; weight gradient: gemm_split_kernel<2 f16 pieces>)",
+              F16X2_PEAK, 3.0,
               "float32 product = 3 f16 MFMA terms: peak = 2500 TFLOP/s f16 dense / 3",
               "float32 in/out; products as 3 f16 MFMA terms of 2-way f16 splits of the operands scaled by powers of two, "
               "f32 accumulate (representation error about one float32 ulp per product)"),

@@ -20,6 +20,10 @@ import sys
 
 # kernel-name fragment -> (operator, counts as one operator launch?)
 RULES = [
+    ("gemm_f16q_kernel<true, false>", "linear_forward", True),           # (TAIL, W transposed)
+    ("gemm_f16q_kernel<false, false>", "linear_forward", True),
+    ("gemm_f16q_kernel<true, true>", "linear_backward_data", True),
+    ("gemm_f16q_kernel<false, true>", "linear_backward_data", True),
     ("gemm_f16p_kernel<true, true, true, 4, 0, 2, false>", "linear_forward", True),     # (… TAIL, paths, NI, -, -, W transposed)
     ("gemm_f16p_kernel<false, true, true, 4, 0, 2, false>", "linear_forward", True),
     ("gemm_f16p_kernel<true, true, true, 4, 0, 2, true>", "linear_backward_data", True),
