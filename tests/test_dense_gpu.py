@@ -442,3 +442,51 @@ def test_linear_with_presplit_weights(oracle, M, N, K, relu, gemm_mode):
     # same pieces, same products, another order of the float32 accumulation: a few ulps of the absolute sum apart
     assert elementwise_excess(y.cpu().numpy(), y_in.cpu().numpy().astype(np.float64), ax @ aw.T + np.abs(b)[None, :]) <= 8.0
     assert elementwise_excess(dx.cpu().numpy(), dx_in.cpu().numpy().astype(np.float64), adz @ aw) <= 8.0
+
+
+_SHAPE_CASE = """
+import sys
+sys.path.insert(0, %(root)r)
+import torch
+from dlrm_amd import ops
+ops.set_gemm_mode(2)
+g = torch.Generator(device="cuda").manual_seed(3)
+out = {}
+for M, N, K in ((16421, 256, 1024), (32805, 300, 479)):
+    Kp = (K + 31) // 32 * 32
+    x = torch.relu(torch.randn(M, Kp, device="cuda", generator=g))[:, :K]
+    w = (torch.randn(N, Kp, device="cuda", generator=g) / K ** 0.5)[:, :K]
+    b = torch.randn(N, device="cuda", generator=g)
+    dz = torch.randn(M, N, device="cuda", generator=g) * (torch.rand(M, N, device="cuda", generator=g) > 0.5)
+    sw = ops.SplitWeights(w)
+    out["y%%d" %% K] = ops.linear_forward(x, w, b, True, w_planes=sw).cpu()
+    out["dx%%d" %% K] = ops.linear_backward_data(dz, w, relu_mask=x, w_planes=sw).cpu()
+    out["ref_y%%d" %% K] = torch.relu(x.double() @ w.double().t() + b.double()).cpu()
+    out["ref_dx%%d" %% K] = ((dz.double() @ w.double()) * (x > 0)).cpu()
+torch.cuda.synchronize()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_both_mfma_shapes_of_the_planes_kernel(tmp_path):
+    """The kernel that reads pre-split weights exists on v_mfma_f32_16x16x32_f16 (the default) and on 32x32x16
+    (DLRM_F16P_SHAPE=32, read once per process: two child processes).  Same pieces, same products, another order of the
+    float32 accumulation: both must meet the float64 product at the tolerance of the other tests, on a ragged batch, a
+    partial last reduction step and a partial last column tile."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "case.py"
+    script.write_text(_SHAPE_CASE % {"root": root})
+    outs = []
+    for name, env in (("s16", {}), ("s32", {"DLRM_F16P_SHAPE": "32"})):
+        out = tmp_path / (name + ".pt")
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(os.environ, **env), timeout=280)
+        outs.append(torch.load(out, weights_only=True))
+    for o in outs:
+        for k in ("y1024", "dx1024", "y479", "dx479"):
+            ref = o["ref_" + k]
+            assert ((o[k].double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6, k
+    for k in ("y1024", "dx1024", "y479", "dx479"):
+        assert ((outs[0][k].double() - outs[1][k].double()).abs().max() / outs[0]["ref_" + k].abs().max()).item() <= 2e-6
