@@ -184,7 +184,7 @@ KERNEL_OF = {
     "interact_dot_forward": "interact_dot_fwd_kernel (interact_dot_fwd_gather_kernel: reads the table rows itself when every "
                             "bag holds one id)",
     "interact_dot_backward": "interact_dot_bwd_kernel",
-    "linear_forward_skinny": "skinny_k_fwd_kernel / gemv_fwd_kernel (13 input columns; one output column)",
+    "linear_forward_skinny": "skinny_k_fwd_kernel (13 input columns) / gemv_fwd_loss_bwd_kernel (one output column: prediction, loss gradient and input gradient)",
     "linear_backward_data_skinny": "gemv_bwd_data_kernel (one output column)",
     "linear_backward_weight_skinny": "skinny_k_bwd_weight_kernel / gemv_bwd_weight_kernel + reduce_slabs",
     "comm_forward_exchange": "RCCL all-to-all of pooled vectors (reduce-scatter for row-wise tables), peers' arrival included",
@@ -207,6 +207,12 @@ def layer_shapes(cfg):
     return list(zip(bsz[:-1], bsz[1:])), list(zip(tsz[:-1], tsz[1:]))
 
 
+def fused_last_layer(layers, i):
+    """model.hip's rule (DLRM_FUSE_LAST=0 switches it off): the last of at least two layers, one output, <= 1024 inputs"""
+    K, N = layers[i]
+    return os.environ.get("DLRM_FUSE_LAST", "1")[:1] != "0" and i == len(layers) - 1 and i >= 1 and N == 1 and K <= 1024 and K % 4 == 0
+
+
 def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gather=False):
     """Algorithmic work of one step on one rank per operator class: (work, "mfma" flops | "hbm" bytes).
     gather: one id per bag, the interaction's forward kernel reads the table rows itself (no EmbeddingBag forward
@@ -218,8 +224,11 @@ def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gathe
     bot, top = layer_shapes(cfg)
     for stack, layers in (("bot", bot), ("top", top)):
         for i, (K, N) in enumerate(layers):
+            # (a training step's last layer: prediction, loss gradient and input gradient in one launch that reads
+            # the input, the labels and writes the three results)
+            fused = stack == "top" and fused_last_layer(layers, i)
             if skinny(K, N):
-                w["linear_forward_skinny"] += 4.0 * B * (N + K)
+                w["linear_forward_skinny"] += 4.0 * B * ((2 * K + 3) if fused else (N + K))
                 w["linear_backward_weight_skinny"] += 4.0 * B * (N + K)
             else:
                 w["linear_forward"] += 2.0 * B * N * K
@@ -227,7 +236,9 @@ def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gathe
             has_dgrad = i > 0 or stack == "top"      # the bottom MLP's first layer needs no input gradient
             if has_dgrad:
                 masked = not (stack == "top" and i == 0)
-                if N == 1:
+                if fused:
+                    pass
+                elif N == 1:
                     w["linear_backward_data_skinny"] += 4.0 * B * (N + K * (2 if masked else 1))
                 else:
                     w["linear_backward_data"] += 2.0 * B * N * K

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "skinny.h"
 
 namespace dlrm {
 
@@ -82,6 +83,7 @@ struct dlrm_model {
     float *amax = nullptr;
     std::vector<char> amax_valid;
     bool f16x2 = false;
+    bool fuse_last = false;  // a training step's last layer, loss gradient and that layer's backward-data pass are one launch
     void *ws_dense = nullptr, *ws_sparse = nullptr, *ws_sparse_rw = nullptr;
     size_t ws_dense_bytes = 0, ws_sparse_bytes = 0, ws_sparse_rw_bytes = 0;
     float *a2a_send = nullptr, *a2a_recv = nullptr, *g_send = nullptr, *g_recv = nullptr, *rw_part = nullptr, *rw_local = nullptr;
@@ -269,7 +271,7 @@ static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t 
 // (it needs the layer's dz only), the chain of data gradients stays on `s`.
 static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const float *x_in, int64_t x_in_ld,
                           const std::vector<Act> &acts, const float *dz_last, int64_t dz_last_ld, const std::vector<Act> &dz_bufs,
-                          float *dx_first, int64_t dx_first_ld, hipStream_t s) {
+                          float *dx_first, int64_t dx_first_ld, hipStream_t s, bool last_dgrad_done = false) {
     const int n = (int)st.size();
     hipStream_t sw = m->s_wgrad ? m->s_wgrad : s;
     std::vector<SlabReduce> pending((size_t)n);
@@ -282,6 +284,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
             if (int rc = need_max(m, st[i].s_dz, dz, st[i].N, dz_ld, m->B, s)) return rc;
         if (int rc = wait_for(m, sw, s)) return rc;      // dz of this layer is complete
         if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw, &pending[(size_t)i])) return rc;
+        if (i == n - 1 && last_dgrad_done) continue;      // (dz_bufs[n - 2] came with the loss gradient)
         if (i > 0) {
             if (int rc = linear_dgrad(m, st[i], 0, st[i].K, dz, dz_ld, dz_bufs[i - 1].p, dz_bufs[i - 1].ld, acts[i - 1].p,
                                       acts[i - 1].ld, s, big_layer(m, st[i - 1]) ? st[i - 1].s_dz : -1))
@@ -473,7 +476,9 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
                 return rc;
     }
     x = m->inter; xl = m->inter_ld;
-    for (size_t i = 0; i < m->topl.size(); i++) {
+    // (the last layer of a training step that fuses it with the loss gradient is launched by the step)
+    const size_t n_top = m->topl.size() - (train && m->fuse_last ? 1 : 0);
+    for (size_t i = 0; i < n_top; i++) {
         const bool relu = m->cfg.final_relu || i + 1 < m->topl.size();
         const int y_slot = i + 1 < m->topl.size() && big_layer(m, m->topl[i + 1]) ? m->topl[i + 1].s_x : -1;
         if (int rc = linear_fwd(m, m->topl[i], x, xl, m->top_acts[i].p, m->top_acts[i].ld, relu, main, y_slot)) return rc;
@@ -699,6 +704,13 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     if ((rc = make_acts(m->top, m->top_dz, m->top.size() - 1))) return fail(rc);
     if ((rc = dalloc(m, &m->dpred, B))) return fail(rc);
     if ((rc = dalloc(m, &m->loss, 1))) return fail(rc);
+    {   // DLRM_FUSE_LAST=0 keeps the last layer, the loss gradient and the layer's backward-data pass apart (for A/B timing)
+        const char *e = getenv("DLRM_FUSE_LAST");
+        const size_t n = m->topl.size();
+        m->fuse_last = !(e && e[0] == '0') && n >= 2 && m->topl[n - 1].N == 1 &&
+                       gemv_forward_loss_backward_ok(m->top_acts[n - 2].p, m->top_acts[n - 2].ld, m->params + m->topl[n - 1].w_off,
+                                                     m->top_dz[n - 2].p, m->top_dz[n - 2].ld, m->topl[n - 1].K);
+    }
 
     // ---- workspaces: the largest any layer / any batch of the configured shape needs
     // (every layer its own share: the partial sums of a stack's layers are added up together, behind the last of them)
@@ -935,8 +947,21 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
     // loss (means over the GLOBAL batch, so the ranks' gradients add): the gradient on the critical path, the
     // value -- one workgroup's fixed-order sum, which nothing downstream reads -- beside the backward pass
     hipStream_t side = m->s_prep ? m->s_prep : main;
+    if (m->fuse_last) {
+        const size_t n = m->topl.size();
+        const Layer &l = m->topl[n - 1];
+        const bool bce = c.loss == DLRM_LOSS_BCE;
+        float *dx_max = m->f16x2 && big_layer(m, m->topl[n - 2]) ? out_slot(m, m->topl[n - 2].s_dz) : nullptr;
+        if (int rc = timed(m, DLRM_TIME_LINEAR_FORWARD_SKINNY, main, [&] {
+                return gemv_forward_loss_backward(m->top_acts[n - 2].p, m->top_acts[n - 2].ld, m->params + l.w_off,
+                                                  m->params + l.b_off, m->labels, m->Bg, bce, m->pred, m->dpred, m->top_dz[n - 2].p,
+                                                  m->top_dz[n - 2].ld, (int)m->B, l.K, c.final_relu, bce ? 0 : c.final_relu, dx_max,
+                                                  main);
+            }))
+            return rc;
+    }
     if (int rc = wait_for(m, side, main)) return rc;    // the predictions are there
-    for (int half = 0; half < 2; half++) {
+    for (int half = m->fuse_last ? 1 : 0; half < 2; half++) {
         float *lo = half ? m->loss : nullptr, *gr = half ? nullptr : m->dpred;
         hipStream_t s = half ? side : main;
         if (c.loss == DLRM_LOSS_BCE) {
@@ -947,7 +972,7 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
     }
     // top MLP backward, interaction backward
     if (m->dot) {
-        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, m->dinter, m->inter_ld, main))
+        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, m->dinter, m->inter_ld, main, m->fuse_last))
             return rc;
         if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_BACKWARD, main, [&] {
                 float *dx0_max = big_layer(m, m->bot.back()) ? out_slot(m, m->bot.back().s_dz) : nullptr;
@@ -958,7 +983,7 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
             }))
             return rc;
     } else {
-        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, nullptr, 0, main)) return rc;
+        if (int rc = stack_backward(m, m->topl, m->inter, m->inter_ld, m->top_acts, m->dpred, 1, m->top_dz, nullptr, 0, main, m->fuse_last)) return rc;
         // the bottom part of the concatenation is a ReLU output, the pooled part is not
         const int nb = m->bottom.back();
         const float *dz0 = m->topl.size() > 1 ? m->top_dz[0].p : m->dpred;

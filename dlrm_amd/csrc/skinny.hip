@@ -1,6 +1,7 @@
 // Kernels for the two layer shapes of a DLRM that are no matrix product (see skinny.h): plain float32
 // fma chains, one pass over the large operand.
 #include "skinny.h"
+#include "loss.h"
 
 #include <stdlib.h>
 
@@ -160,6 +161,70 @@ __global__ __launch_bounds__(kSkThreads) void gemv_bwd_data_kernel(const float *
     if (dx_max != nullptr) fold_absmax_block(vmax, dx_max);
 }
 
+// The one-column last layer of a training step in one sweep over its input: y = act(x . w + b) (the prediction, summed
+// in gemv_fwd_kernel's order), d(loss)/dy of the sample, and dx = dy w where x > 0 (x is a ReLU output).  A group of 16
+// lanes owns a row and keeps its KI float4 pieces in registers between the dot product and the gradient; the
+// separate kernels read x twice and are three launches on the step's critical path.
+template <bool BCE, int KI>
+__global__ __launch_bounds__(kSkThreads) void gemv_fwd_loss_bwd_kernel(const float *__restrict__ x, int64_t x_ld,
+                                                                        const float *__restrict__ w, const float *__restrict__ bias,
+                                                                        const float *__restrict__ target, int64_t mean_over,
+                                                                        float *__restrict__ y, float *__restrict__ dy,
+                                                                        float *__restrict__ dx, int64_t dx_ld, int M, int K,
+                                                                        int relu, int relu_mask, float *__restrict__ dx_max) {
+    const int lig = threadIdx.x & 15;
+    const float b = bias ? bias[0] : 0.f;
+    const float inv_n = 1.0f / (float)mean_over;
+    float4 wv[KI];
+#pragma unroll
+    for (int i = 0; i < KI; i++) {
+        const int k = lig * 4 + 64 * i;
+        wv[i] = k < K ? *reinterpret_cast<const float4 *>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float vmax = 0.f;
+    for (int m = blockIdx.x * (kSkThreads / 16) + (threadIdx.x >> 4); m < M; m += gridDim.x * (kSkThreads / 16)) {
+        const float *xr = x + (int64_t)m * x_ld;
+        float4 xv[KI];
+#pragma unroll
+        for (int i = 0; i < KI; i++) {
+            const int k = lig * 4 + 64 * i;
+            xv[i] = k < K ? *reinterpret_cast<const float4 *>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float t = target[m];
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < KI; i++)
+            if (lig * 4 + 64 * i < K) {
+                a = fmaf(xv[i].x, wv[i].x, a); a = fmaf(xv[i].y, wv[i].y, a);
+                a = fmaf(xv[i].z, wv[i].z, a); a = fmaf(xv[i].w, wv[i].w, a);
+            }
+        // (a butterfly: both lanes of a pair add the same two numbers, so all 16 end with the same bits)
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
+        a += b;
+        a = relu ? fmaxf(a, 0.f) : a;
+        float term;
+        const float g = loss_grad<BCE>(a, t, inv_n, relu_mask, term);
+        if (lig == 0) {
+            y[m] = a;
+            dy[m] = g;
+        }
+        float *dr = dx + (int64_t)m * dx_ld;
+#pragma unroll
+        for (int i = 0; i < KI; i++) {
+            const int k = lig * 4 + 64 * i;
+            if (k < K) {
+                float4 r = make_float4(g * wv[i].x, g * wv[i].y, g * wv[i].z, g * wv[i].w);
+                r.x = xv[i].x > 0.f ? r.x : 0.f; r.y = xv[i].y > 0.f ? r.y : 0.f;
+                r.z = xv[i].z > 0.f ? r.z : 0.f; r.w = xv[i].w > 0.f ? r.w : 0.f;
+                *reinterpret_cast<float4 *>(dr + k) = r;
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            }
+        }
+    }
+    if (dx_max != nullptr) fold_absmax_block(vmax, dx_max);
+}
+
 // thread (row lane, column quad): K/4 quads side by side, 256 / (K/4) row lanes; partial sums meet in LDS
 __global__ __launch_bounds__(kSkThreads) void gemv_bwd_weight_kernel(const float *__restrict__ dz, int64_t dz_ld,
                                                                       const float *__restrict__ x, int64_t x_ld,
@@ -271,6 +336,32 @@ int gemv_backward_data(const float *dz, int64_t dz_ld, const float *w, float *dx
     const int64_t cap = dx_max ? 2048 : 8192;     // (fewer, longer workgroups when each ends with an atomic)
     hipLaunchKernelGGL(gemv_bwd_data_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(kSkThreads), 0, s, dz, dz_ld, w,
                        dx, dx_ld, mask, mask_ld, M, K, dx_max);
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+bool gemv_forward_loss_backward_ok(const void *x, int64_t x_ld, const void *w, const void *dx, int64_t dx_ld, int K) {
+    return gemv_ok(x, x_ld, w, K) && gemv_ok(dx, dx_ld, w, K) && K <= 1024;
+}
+
+template <bool BCE, int KI>
+static void launch_fwd_loss_bwd(unsigned grid, hipStream_t s, const float *x, int64_t x_ld, const float *w, const float *bias,
+                                const float *target, int64_t mean_over, float *y, float *dy, float *dx, int64_t dx_ld, int M, int K,
+                                int relu, int relu_mask, float *dx_max) {
+    hipLaunchKernelGGL((gemv_fwd_loss_bwd_kernel<BCE, KI>), dim3(grid), dim3(kSkThreads), 0, s, x, x_ld, w, bias, target, mean_over,
+                       y, dy, dx, dx_ld, M, K, relu, relu_mask, dx_max);
+}
+
+int gemv_forward_loss_backward(const float *x, int64_t x_ld, const float *w, const float *bias, const float *target,
+                               int64_t mean_over, bool bce, float *y, float *dy, float *dx, int64_t dx_ld, int M, int K, int relu,
+                               int relu_mask, float *dx_max, hipStream_t s) {
+    const int64_t blocks = ceil_div(M, kSkThreads / 16);
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+#define DLRM_FLB(B, KI) launch_fwd_loss_bwd<B, KI>(grid, s, x, x_ld, w, bias, target, mean_over, y, dy, dx, dx_ld, M, K, relu, relu_mask, dx_max)
+    if (K <= 256) { if (bce) DLRM_FLB(true, 4); else DLRM_FLB(false, 4); }
+    else if (K <= 512) { if (bce) DLRM_FLB(true, 8); else DLRM_FLB(false, 8); }
+    else { if (bce) DLRM_FLB(true, 16); else DLRM_FLB(false, 16); }
+#undef DLRM_FLB
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

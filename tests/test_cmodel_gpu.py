@@ -282,3 +282,58 @@ def test_c_hosted_graphed_steps_equal_direct_launches(one_id, gemm):
         got = run(stream, graph_steps=True)
         for what, a, b in zip(("tables", "dense parameters", "predictions", "losses"), ref, got):
             assert torch.equal(a, b), "%s: %s differ from the direct launches" % (name, what)
+
+
+_FUSE_CASE = """
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+from dlrm_amd.cmodel import CModel
+from dlrm_amd.model import DLRMConfig
+from tests.oracle_model import make_batch
+from tests.test_cmodel_gpu import local_batch_ids
+out = {}
+for tag, last, loss in (("a", 64, "bce"), ("b", 320, "mse"), ("c", 1024, "bce"), ("d", 1028, "bce")):
+    cfg = DLRMConfig(table_rows=[50, 300, 7], dim=16, dense_in=13, bottom=[32, 16], top=[48, last, 1], lr=0.01, loss=loss,
+                     final_relu=loss == "mse")
+    B = 1037
+    m = CModel(cfg, B, seed=5, idx_dtype=torch.int64)
+    m.init_dense(11)
+    rng = np.random.default_rng(23)
+    for step in range(2):
+        dense, idx, off, labels = make_batch(rng, cfg, B, False)
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        li, lo = local_batch_ids(m, cfg, idx, off, B)
+        loss_v = m.train_step(torch.from_numpy(li).cuda(), torch.from_numpy(lo).cuda())
+        torch.cuda.synchronize()
+        assert int(m.err_flag.item()) == 0
+        out[tag + "loss%%d" %% step] = loss_v.cpu().clone()
+        out[tag + "pred%%d" %% step] = m.pred.cpu().clone()
+    Ws, bs = m.get_dense()
+    for i, a in enumerate(Ws + bs):
+        out[tag + "p%%d" %% i] = torch.from_numpy(np.ascontiguousarray(a))
+    m.close()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_c_hosted_fused_last_layer_equals_the_three_launches(tmp_path):
+    """A training step evaluates the one-column last layer, the loss gradient and that layer's backward-data pass in
+    one launch (up to 1024 inputs; 1028 keeps the separate kernels).  DLRM_FUSE_LAST=0 (read when the model is made:
+    two child processes) launches the three kernels: predictions, losses and every dense parameter after two steps
+    carry the same bits, with both losses, with and without the output ReLU, on a batch that is no multiple of 16."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "case.py"
+    script.write_text(_FUSE_CASE % {"root": root})
+    outs = []
+    for name, env in (("fused", {}), ("apart", {"DLRM_FUSE_LAST": "0"})):
+        out = tmp_path / (name + ".pt")
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=dict(os.environ, **env), timeout=280)
+        outs.append(torch.load(out, weights_only=True))
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) > 20
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

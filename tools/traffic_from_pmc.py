@@ -40,6 +40,7 @@ RULES = [
     ("split_weights_kernel", "operand_maxima", False),
     ("skinny_k_fwd_kernel", "linear_forward_skinny", True),
     ("gemv_fwd_kernel", "linear_forward_skinny", True),
+    ("gemv_fwd_loss_bwd_kernel", "linear_forward_skinny", True),
     ("gemv_bwd_data_kernel", "linear_backward_data_skinny", True),
     ("skinny_k_bwd_weight_kernel", "linear_backward_weight_skinny", True),
     ("gemv_bwd_weight_kernel", "linear_backward_weight_skinny", True),
