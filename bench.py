@@ -183,7 +183,7 @@ KERNEL_OF = {
                                "overlapped with the forward pass)",
     "interact_dot_forward": "interact_dot_fwd_kernel (interact_dot_fwd_gather_kernel: reads the table rows itself when every "
                             "bag holds one id)",
-    "interact_dot_backward": "interact_dot_bwd_kernel",
+    "interact_dot_backward": "interact_dot_bwd_kernel (interact_dot_bwd_gather_kernel: gathers the table rows again when the forward kernel did)",
     "linear_forward_skinny": "skinny_k_fwd_kernel (13 input columns) / gemv_fwd_loss_bwd_kernel (one output column: prediction, loss gradient and input gradient)",
     "linear_backward_data_skinny": "gemv_bwd_data_kernel (one output column)",
     "linear_backward_weight_skinny": "skinny_k_bwd_weight_kernel / gemv_bwd_weight_kernel + reduce_slabs",
@@ -252,10 +252,13 @@ def step_work(cfg, B, Bg, world, Tl, Trw, uniq, uniq_rw, idx_esz, row_esz, gathe
     out["embbag_backward_prepare"] = (0.0, "hbm")
     if cfg.interaction == "dot":
         F = cfg.num_features
-        # gather: the forward kernel also reads a bag's id and offset and leaves a copy of the [F, D] block
-        extra = 2 * (F - 1) * idx_esz + F * D * 4 if gather else 0
-        out["interact_dot_forward"] = (B * ((F * D + D + F * (F - 1) // 2) * 4 + extra), "hbm")
-        out["interact_dot_backward"] = (B * (2 * F * D + D + F * (F - 1) // 2) * 4, "hbm")
+        # gather: the forward kernel also reads a bag's id and offset; the backward kernel gathers the rows again and
+        # reads them as well (DLRM_GATHER_BWD=0: the forward kernel leaves a copy of the [F, D] block for it instead)
+        ids = 2 * (F - 1) * idx_esz if gather else 0
+        gather_bwd = gather and os.environ.get("DLRM_GATHER_BWD", "1")[:1] != "0"
+        copy = F * D * 4 if gather and not gather_bwd else 0
+        out["interact_dot_forward"] = (B * ((F * D + D + F * (F - 1) // 2) * 4 + ids + copy), "hbm")
+        out["interact_dot_backward"] = (B * ((2 * F * D + D + F * (F - 1) // 2) * 4 + (ids if gather_bwd else 0)), "hbm")
     return out
 
 

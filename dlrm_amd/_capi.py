@@ -22,7 +22,7 @@ class DlrmError(RuntimeError):
     pass
 
 
-ABI_VERSION = 1017   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
+ABI_VERSION = 1018   # DLRM_ABI_VERSION of include/dlrm_amd.h these structures mirror
 
 
 class EmbBagDesc(C.Structure):

@@ -138,6 +138,8 @@ int pair_sort(uint64_t *keys_a, uint64_t *keys_b, int32_t *vals_a, int32_t *vals
 // magnitude of the interaction's output / of feature 0's gradient, folded into a slot like the GEMM epilogues do
 int interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,
                                     float *d_x_copy, float *d_out_max, dlrm_stream_t stream);
+int interact_dot_backward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, const float *d_dout, int64_t dout_ld,
+                                     float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max, dlrm_stream_t stream);
 int interact_dot_backward_max(const float *d_x, const float *d_dout, int64_t dout_ld, int64_t B, int32_t F, int32_t D,
                               float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max, dlrm_stream_t stream);
 // ... and the same for the kernels that read / write the features through views

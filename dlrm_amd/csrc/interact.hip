@@ -427,6 +427,95 @@ __global__ __launch_bounds__(kIntThreads, 2) void interact_dot_fwd_gather_kernel
     if (out_max != nullptr) fold_absmax_block(vmax, out_max);
 }
 
+// The backward kernel with the same lookup folded in: a training step whose forward pass gathered the rows itself
+// gathers them again here (the tables are not touched between the two) instead of having the forward kernel write a
+// copy of the [B, F, D] block and reading that: the forward pass writes F*D*4 bytes per sample less, this kernel reads
+// the same bytes from the tables that it would read from the copy.  Same chunks of 32 samples, same id checks (a
+// lookup that counted as a zero row in the forward pass counts as one here).
+template <int NV, typename IdxT>
+__global__ __launch_bounds__(kIntThreads, 2) void interact_dot_bwd_gather_kernel(GatherArgs g, const float *__restrict__ dout,
+                                                                               int64_t dout_ld, int64_t B, int F, int D,
+                                                                               float *__restrict__ dx, int relu_mask0,
+                                                                               float *__restrict__ dx0_max) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = D + 4;
+    const int per_wave = F * ld + F * kSLd + 4;
+    float vmax0 = 0.f;
+    float *sx = smem + (size_t)wave * per_wave;
+    float *ss = sx + F * ld;
+    int *sidx = reinterpret_cast<int *>(smem + (size_t)kIntWaves * per_wave);
+    for (int i = lane; i < F * kSLd + 4; i += 64) ss[i] = 0.f;
+    const int n_pairs = F * (F - 1) / 2;
+    const int n4 = F * D / 4;
+    constexpr int kMaxPairs = (kFP * (kFP - 1) / 2 + 63) / 64;   // 8
+    int pij[kMaxPairs];   // (i << 8) | j of this lane's pair gradients, -1 past the last pair
+#pragma unroll
+    for (int u = 0; u < kMaxPairs; u++) {
+        const int c = lane + 64 * u;
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)c)) * 0.5f);
+        while (i * (i - 1) / 2 > c) i--;
+        while ((i + 1) * i / 2 <= c) i++;
+        pij[u] = c < n_pairs ? (i << 8) | (c - i * (i - 1) / 2) : -1;
+    }
+    const int last_idx = min(lane + 64 * (NV - 1), n4 - 1);
+    f32x4 pre[NV];
+    float pg[kMaxPairs];
+    auto fetch_grad = [&](int64_t bb) {
+        const float *go = dout + bb * dout_ld + D;
+#pragma unroll
+        for (int u = 0; u < kMaxPairs; u++) pg[u] = go[pij[u] >= 0 ? lane + 64 * u : 0];
+    };
+    const int64_t n_chunks = (B + kChunk - 1) / kChunk;
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const int64_t b0 = c * kChunk;
+        __syncthreads();     // the previous chunk's ids are no longer needed
+        stage_ids<IdxT>(g, B, b0, sidx);
+        __syncthreads();
+        int j = wave;
+        if (b0 + j < B) {
+            gather_fetch<NV>(g, sidx, j, b0 + j, n4, D, ld, lane, pre);
+            fetch_grad(b0 + j);
+        }
+        for (; j < kChunk && b0 + j < B; j += kIntWaves) {
+            const int64_t b = b0 + j;
+            gather_park<NV>(sx, n4, D, ld, lane, pre);
+#pragma unroll
+            for (int u = 0; u < kMaxPairs; u++) {
+                const bool real = pij[u] >= 0;
+                const int i = pij[u] >> 8, jj = pij[u] & 255;
+                const float gv = real ? pg[u] : 0.f;
+                ss[real ? i * kSLd + jj : F * kSLd] = gv;     // lanes past the last pair write the spare cell
+                ss[real ? jj * kSLd + i : F * kSLd] = gv;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            {   // the next sample's loads fly behind the MFMAs (the chunk's last one re-reads itself)
+                const int jn = (j + kIntWaves < kChunk && b + kIntWaves < B) ? j + kIntWaves : j;
+                gather_fetch<NV>(g, sidx, jn, b0 + jn, n4, D, ld, lane, pre);
+                fetch_grad(b0 + jn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                int lds_off[NV];   // (unused by a bwd_sample that leaves the store to its caller)
+#pragma unroll
+                for (int u = 0; u < NV; u++) lds_off[u] = 0;
+                bwd_sample<NV>(sx, ss, F, D, ld, dout + b * dout_ld, nullptr, lds_off, last_idx, relu_mask0, lane, vmax0);
+            }
+            {
+                float *gx = dx + b * (int64_t)(F * D);
+                const int lv = opaque(lane);
+#pragma unroll
+                for (int u = 0; u < NV; u++)
+                    reinterpret_cast<f32x4 *>(gx)[min(lane + 64 * u, n4 - 1)] =
+                        *reinterpret_cast<const f32x4 *>(sx + vec_place(lv, u, n4, D, ld).lds);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (dx0_max != nullptr) fold_absmax_block(vmax0, dx0_max);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Both kernels on features that do not sit in one [B, F, D] block: feature f of sample b is D floats at
 // base[f] + b * stride[f].  A sharded rank receives the pooled vectors as one block per source rank and sends the
@@ -701,6 +790,52 @@ int dlrm::interact_dot_forward_gather_max(const dlrm_embbag *e, const float *d_x
         default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
     }
 #undef DLRM_INT_FWDG
+    DLRM_LAUNCH_CHECK();
+    return DLRM_OK;
+}
+
+extern "C" int dlrm_interact_dot_backward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, const float *d_dout,
+                                                 int64_t dout_ld, float *d_dx, int32_t relu_mask_feature0, dlrm_stream_t stream) {
+    return dlrm::interact_dot_backward_gather_max(e, d_x0, x0_ld, d_dout, dout_ld, d_dx, relu_mask_feature0, nullptr, stream);
+}
+
+// the same launch; d_dx0_max (or NULL): max |gradient of feature 0| is folded into it
+int dlrm::interact_dot_backward_gather_max(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, const float *d_dout,
+                                           int64_t dout_ld, float *d_dx, int32_t relu_mask_feature0, float *d_dx0_max,
+                                           dlrm_stream_t stream) {
+    GatherArgs g{};
+    if (int rc = check_gather(e, d_x0, x0_ld, &g)) return rc;
+    const int64_t B = e->batch;
+    const int F = e->num_tables + 1, D = e->dim;
+    if (B == 0) return DLRM_OK;
+    DLRM_REQUIRE(d_dout != nullptr && d_dx != nullptr && dout_ld >= D + F * (F - 1) / 2, "dout/dx is NULL or dout_ld too small");
+    DLRM_REQUIRE(reinterpret_cast<uintptr_t>(d_dx) % 16 == 0, "dx must be 16-byte aligned");
+    const size_t lds = sizeof(float) * kIntWaves * ((size_t)F * (D + 4) + F * kSLd + 4) + sizeof(int) * (size_t)g.T * kChunk;
+    const int64_t want = ceil_div(B, kChunk);
+    const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+    const int nv = (F * D / 4 + 63) / 64;
+    const bool i64 = e->idx_dtype == DLRM_I64;
+#define DLRM_INT_BWDG(NV)                                                                                              \
+    case NV:                                                                                                           \
+        if (i64) {                                                                                                     \
+            DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_gather_kernel<NV, int64_t>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+            hipLaunchKernelGGL((interact_dot_bwd_gather_kernel<NV, int64_t>), dim3(blocks), dim3(kIntThreads), lds,    \
+                               as_stream(stream), g, d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0, d_dx0_max);   \
+        } else {                                                                                                       \
+            DLRM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(interact_dot_bwd_gather_kernel<NV, int32_t>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+            hipLaunchKernelGGL((interact_dot_bwd_gather_kernel<NV, int32_t>), dim3(blocks), dim3(kIntThreads), lds,    \
+                               as_stream(stream), g, d_dout, dout_ld, B, F, D, d_dx, relu_mask_feature0, d_dx0_max);   \
+        }                                                                                                              \
+        break;
+    switch (nv) {
+        DLRM_INT_BWDG(1) DLRM_INT_BWDG(2) DLRM_INT_BWDG(3) DLRM_INT_BWDG(4) DLRM_INT_BWDG(5) DLRM_INT_BWDG(6) DLRM_INT_BWDG(7)
+        DLRM_INT_BWDG(8) DLRM_INT_BWDG(9) DLRM_INT_BWDG(10) DLRM_INT_BWDG(11) DLRM_INT_BWDG(12) DLRM_INT_BWDG(13)
+        DLRM_INT_BWDG(14) DLRM_INT_BWDG(15) DLRM_INT_BWDG(16)
+        default: return set_error(DLRM_ERR_INVALID, "F*D = %d is too large for the dot interaction kernel (max 4096)", F * D);
+    }
+#undef DLRM_INT_BWDG
     DLRM_LAUNCH_CHECK();
     return DLRM_OK;
 }

@@ -56,6 +56,7 @@ struct dlrm_model {
     int64_t Bg;
     bool sharded, dot;
     bool gather = false;     // one id per bag: the interaction kernels read the rows themselves
+    bool gather_bwd = true;  // ... the backward kernel too (false: the forward kernel leaves a copy of the block for it)
     bool views = false;      // sharded: the interaction reads / writes the exchange buffers in place (no unpack / pack)
     std::vector<dlrm_feature_view> x_views, dx_views;
     // placement
@@ -455,10 +456,11 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
         // one id per bag: feature f >= 1 of a sample is a table row, read inside the interaction kernel
         dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
         if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
-                // (a training step whose backward pass reads the block gets it written in place around feature 0)
+                // (a training step whose backward pass reads the block -- not the one that gathers the rows again --
+                // gets it written in place around feature 0)
                 float *out_max = big_layer(m, m->topl[0]) ? out_slot(m, m->topl[0].s_x) : nullptr;
                 return interact_dot_forward_gather_max(&e, m->feat, m->feat_ld, m->inter, m->inter_ld,
-                                                       train ? m->feat : nullptr, out_max, main);
+                                                       train && !m->gather_bwd ? m->feat : nullptr, out_max, main);
             }))
             return rc;
         if (int rc = launch_prepare()) return rc;
@@ -545,6 +547,10 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
     m->sharded = sharded; m->dot = c->interaction == DLRM_INTERACT_DOT;
     m->gather = c->one_id_per_bag && !sharded && m->dot && c->row_dtype == DLRM_F32 && c->num_tables + 1 <= 32 &&
                 (c->dim & (c->dim - 1)) == 0 && c->dim >= 8 && (int64_t)(c->num_tables + 1) * c->dim <= 4096;
+    {   // DLRM_GATHER_BWD=0: the forward kernel leaves a copy of the gathered block for the backward pass (for A/B timing)
+        const char *e = getenv("DLRM_GATHER_BWD");
+        m->gather_bwd = !(e && e[0] == '0');
+    }
     m->table_rows.assign(c->table_rows, c->table_rows + m->T);
     m->bottom.assign(c->bottom, c->bottom + c->n_bottom);
     m->top.assign(c->top, c->top + c->n_top);
@@ -979,6 +985,10 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
                 if (m->views)   // gradients straight into the send blocks of the backward exchange
                     return interact_dot_backward_views_max(m->x_views.data(), m->dinter, m->inter_ld, m->B, m->F, m->D,
                                                            m->dx_views.data(), 1, dx0_max, main);
+                if (m->gather && m->gather_bwd) {     // the tables are as the forward pass read them: their update comes later
+                    dlrm_embbag e = table_desc(m, false, d_indices, d_offsets, n_indices);
+                    return interact_dot_backward_gather_max(&e, m->feat, m->feat_ld, m->dinter, m->inter_ld, m->dfeat, 1, dx0_max, main);
+                }
                 return interact_dot_backward_max(m->feat, m->dinter, m->inter_ld, m->B, m->F, m->D, m->dfeat, 1, dx0_max, main);
             }))
             return rc;

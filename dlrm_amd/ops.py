@@ -399,6 +399,22 @@ def interact_dot_forward_gather(weight, indices, offsets, batch, num_tables, tab
     return out
 
 
+def interact_dot_backward_gather(weight, indices, offsets, batch, num_tables, table_row_offsets, x0, dout, relu_mask_feature0=False,
+                                 out=None, error_flag=None, include_last_offset=False):
+    """interact_dot_backward on x = [x0 | one row per table] with the rows read from the tables again (the backward
+    pass of interact_dot_forward_gather called without x_copy).  Returns dx [B, F, D]."""
+    d = make_embbag_desc(weight, indices, offsets, batch, num_tables, table_row_offsets, _capi.POOL_SUM,
+                         include_last_offset, error_flag)
+    _require_cuda(x0, dout, out)
+    F, D = num_tables + 1, weight.shape[1]
+    if out is None:
+        out = torch.empty((batch, F, D), dtype=torch.float32, device=weight.device)
+    assert out.is_contiguous() and out.numel() == batch * F * D and out.dtype == torch.float32
+    check(_capi.lib().dlrm_interact_dot_backward_gather(C.byref(d), _ptr(x0), C.c_int64(_ld(x0)), _ptr(dout), C.c_int64(_ld(dout)),
+                                                        _ptr(out), C.c_int32(int(relu_mask_feature0)), _stream()))
+    return out
+
+
 def _views(ts, D):
     v = (_capi.FeatureView * len(ts))()
     for it, t in zip(v, ts):

@@ -55,7 +55,7 @@ const char *dlrm_last_error(void);
  * dlrm_version() is what the loaded library was built with; a caller compiled against another
  * DLRM_ABI_VERSION must not pass structs to it (the adapter and the Python binding check this
  * before their first call). */
-#define DLRM_ABI_VERSION 1017
+#define DLRM_ABI_VERSION 1018
 int dlrm_version(void);
 /* Name of the device architecture the kernels were built for ("gfx950"). */
 const char *dlrm_target_arch(void);
@@ -367,6 +367,20 @@ int dlrm_interact_dot_backward(const float *d_x, const float *d_dout, int64_t do
  */
 int dlrm_interact_dot_forward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, float *d_out, int64_t out_ld,
                                      float *d_x_copy, dlrm_stream_t stream);
+
+/*
+ * The backward pass of dlrm_interact_dot_forward_gather with the same lookup folded in: the rows are gathered from the
+ * tables again (the caller has not updated them since the forward pass) instead of being read from a copy that the
+ * forward pass would have to write (d_x_copy = NULL there: F * dim * 4 bytes per sample less to write, the same bytes
+ * to read here).  `e`, d_x0 / x0_ld as in the forward call; d_dout [B, dout_ld] is the gradient of the forward output,
+ * d_dx [B, F, dim] (dense) receives the gradient of every feature -- bit for bit what dlrm_interact_dot_backward writes
+ * when given the gathered block -- feature 0's zeroed where d_x0 <= 0 if relu_mask_feature0 != 0
+ * (src/dlrmtest.cpp:265-267 concatenates a ReLU output).  The ids are checked as in the forward pass and a
+ * violation counts as a zero row.  The reference's autograd differentiates the concat and the gathered rows
+ * separately; it has no fused counterpart.
+ */
+int dlrm_interact_dot_backward_gather(const dlrm_embbag *e, const float *d_x0, int64_t x0_ld, const float *d_dout,
+                                      int64_t dout_ld, float *d_dx, int32_t relu_mask_feature0, dlrm_stream_t stream);
 
 /*
  * The dot interaction on features that do not sit in one [B, F, dim] block: feature f of sample b is dim floats at

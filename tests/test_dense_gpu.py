@@ -275,7 +275,8 @@ def test_interact_dot(oracle, B, F, D):
 def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtype):
     """One id per bag: the interaction forward that reads the rows straight from the tables gives, bit for bit, what
     EmbeddingBag forward + the interaction on its output give (same arithmetic on the same values), and its optional
-    copy of the gathered block equals the pooled block; the output matches the oracle to 1e-5.  A bag that is not one id and an id outside its table
+    copy of the gathered block equals the pooled block; the output matches the oracle to 1e-5.  The backward kernel that
+    gathers the rows again gives, bit for bit, the gradient of the backward kernel that is handed the block.  A bag that is not one id and an id outside its table
     raise the error flag (2 / 1) and count as zero rows."""
     from dlrm_amd import ops
     rng = np.random.default_rng(B + T + D)
@@ -309,6 +310,15 @@ def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtyp
     assert torch.equal(out2, ref_out) and torch.equal(x2, x)
     z_ref = oracle.interact_dot_forward(x.cpu().numpy())
     assert rel_err(out[:, :n_out].cpu().numpy(), z_ref) <= 1e-5
+    # the backward pass that gathers the rows again (no copy of the block) writes what the one given the block writes
+    dout = torch.from_numpy(rng.standard_normal((B, out_ld)).astype(np.float32)).cuda()
+    for mask in (False, True):
+        dx_ref = ops.interact_dot_backward(x, dout, relu_mask_feature0=mask)
+        dx = ops.interact_dot_backward_gather(weight, indices, offsets, B, T, d_tro, x0, dout, relu_mask_feature0=mask,
+                                              error_flag=flag, include_last_offset=True)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        assert torch.equal(dx, dx_ref)
     # violations: an id outside its table -> flag 1; a bag that is not exactly one id -> flag 2; both count as zero rows
     bad = indices.clone()
     bad[B // 2] = rows[0] + 5
@@ -319,6 +329,12 @@ def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtyp
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
     assert torch.equal(out_bad, ops.interact_dot_forward(x_bad, out_ld=out_ld))
+    flag.zero_()
+    dx_bad = ops.interact_dot_backward_gather(weight, bad, offsets, B, T, d_tro, x0, dout, relu_mask_feature0=True,
+                                              error_flag=flag, include_last_offset=True)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    assert torch.equal(dx_bad, ops.interact_dot_backward(x_bad, dout, relu_mask_feature0=True))
     flag.zero_()
     off2 = offsets.clone()
     off2[(T - 1) * B + 3] -= 1
