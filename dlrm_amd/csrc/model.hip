@@ -408,6 +408,11 @@ static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t
 
 static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, bool train, hipStream_t main) {
     hipStream_t emb = m->s_emb ? m->s_emb : main;
+    // the embedding side (lookups, and the exchange of a sharded model: the longest chain ahead of the interaction) needs
+    // what the main stream holds at the call -- the caller's ids, earlier readers of its buffers -- and nothing of what
+    // this pass puts there first (operand maxima, weight planes): its event is recorded before those
+    if (!m->gather)
+        if (int rc = wait_for(m, emb, main)) return rc;
     if (int rc = begin_pass_maxima(m, main)) return rc;
     // The sort of the batch's ids (first half of the sparse update) runs on its own stream from HERE on the device --
     // behind everything the main stream holds at this point -- but its dozen launches are handed to the driver only
@@ -440,10 +445,8 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
     };
     if (prep == main)      // (no stream of its own: program order is device order)
         if (int rc = launch_prepare()) return rc;
-    if (!m->gather) {
-        if (int rc = wait_for(m, emb, main)) return rc;   // earlier readers of feat and the input copies are done
+    if (!m->gather)
         if (int rc = emb_forward(m, idx, off, n_idx, emb)) return rc;
-    }
     // bottom MLP on main
     const float *x = m->x_dense;
     int64_t xl = m->x_ld;
@@ -465,7 +468,9 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
             return rc;
         if (int rc = launch_prepare()) return rc;
     } else {
-        if (int rc = launch_prepare()) return rc;
+        // (the event goes to the embedding stream ahead of the sort's launches: two streams may share a hardware queue,
+        //  a queue runs its packets in order, and an event recorded behind the sort would make the interaction wait
+        //  for the sort as well as for the exchange)
         if (int rc = wait_for(m, main, emb)) return rc;
         if (m->dot)
             if (int rc = timed(m, DLRM_TIME_INTERACT_DOT_FORWARD, main, [&] {
@@ -476,6 +481,7 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
                     return dlrm_interact_dot_forward(m->feat, m->B, m->F, m->D, m->inter, m->inter_ld, main);
                 }))
                 return rc;
+        if (int rc = launch_prepare()) return rc;
     }
     x = m->inter; xl = m->inter_ld;
     // (the last layer of a training step that fuses it with the loss gradient is launched by the step)
