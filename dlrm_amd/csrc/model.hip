@@ -1035,9 +1035,11 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
         if (int rc = timed(m, DLRM_TIME_COMM_ALL_REDUCE, main, [&] { return dlrm_comm_all_reduce_sum(cd, m->grads, m->n_params, main); }))
             return rc;
     }
+    // (the dense update does not wait for the sparse one: in a sharded step the backward exchange and the rows' update
+    //  end after the dense gradients are complete)
+    if (int rc = dlrm_sgd_step(m->params, m->grads, m->n_params, c.lr, main)) return rc;
     if (int rc = wait_for(m, main, emb)) return rc;      // rows are updated before anyone reuses dfeat
-    if (int rc = wait_for(m, main, side)) return rc;     // the loss value is there before anyone overwrites the predictions
-    return dlrm_sgd_step(m->params, m->grads, m->n_params, c.lr, main);
+    return wait_for(m, main, side);                      // the loss value is there before anyone overwrites the predictions
 }
 
 extern "C" int dlrm_model_enable_timing(dlrm_model *m, uint32_t class_mask, int32_t max_records) {
