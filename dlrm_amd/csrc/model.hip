@@ -1019,9 +1019,17 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
             return rc;
     }
     // sparse rows (exchange + fused update) on the embedding stream beside the bottom MLP's backward
-    if (int rc = wait_for(m, emb, main)) return rc;     // dfeat is complete
-    if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, emb)) return rc;
+    // Without a stream of its own the sparse update goes behind the bottom MLP's data gradients: ahead of them it would
+    // only delay the events the weight-gradient stream waits for (small batches: that stream's chain is the step's tail).
+    static const bool emb_last_ok = [] { const char *e = getenv("DLRM_EMB_LAST"); return !(e && e[0] == '0'); }();
+    const bool emb_last = emb == main && m->s_wgrad != nullptr && emb_last_ok;
+    if (!emb_last) {
+        if (int rc = wait_for(m, emb, main)) return rc;     // dfeat is complete
+        if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, emb)) return rc;
+    }
     if (int rc = stack_backward(m, m->bot, m->x_dense, m->x_ld, m->bot_acts, m->dfeat, m->feat_ld, m->bot_dz, nullptr, 0, main)) return rc;
+    if (emb_last)
+        if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, main)) return rc;
     if (m->s_wgrad)
         if (int rc = wait_for(m, main, m->s_wgrad)) return rc;   // every dense gradient is there
     if (early_reduce) {
