@@ -401,13 +401,10 @@ def run_c_host(args, cfg, Bg, B, rank, world, dev):
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
-    t_enqueued = time.perf_counter() - t0      # (the host's share: how long it took to hand the steps to the driver)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if os.environ.get("DLRM_BENCH_ENQUEUE"):
-        print("host enqueue %.4f ms/step of %.4f ms/step" % (1e3 * t_enqueued / args.steps, 1e3 * dt / args.steps), file=sys.stderr)
     if int(model.err_flag.item()) != 0:
         raise SystemExit("out-of-range embedding index reported by the kernels")
     dt_rank = dt

@@ -6,8 +6,7 @@
 // Host code only: every computation is one of the library's own C-ABI operators, launched on up to four
 // streams -- the caller's ("main"), "emb" (EmbeddingBag kernels and their exchanges beside the bottom MLP),
 // "prep" (the sparse update's sort, which needs the ids only, beside the forward pass) and "wgrad" (weight
-// gradients beside the chain of data gradients at small batches).  Below a local batch of 8192 the launches of "prep"
-// and "wgrad" are handed to the driver by a second host thread (SideLauncher).
+// gradients beside the chain of data gradients at small batches).
 //
 // Sharded over the ranks of a dlrm_comm (one process per GPU, RCCL): every rank looks its tables up for the
 // GLOBAL batch.  Whole tables: pooled vectors go to the rank that owns each batch slice with one all-to-all,
@@ -19,15 +18,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <atomic>
-#include <chrono>
 #include <cmath>
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <mutex>
-#include <string>
-#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -51,101 +42,6 @@ struct Layer {
 struct Act {   // a [B, n] activation: pointer + leading dimension
     float *p = nullptr;
     int64_t ld = 0;
-};
-
-
-// A second host thread for the launches of the side streams.  At small batches a step is ~50 launches of 5-50 us
-// kernels and the host needs as long to hand them to the driver as the device needs to run them (Criteo-Kaggle shape:
-// 0.35 ms either way): the calling thread keeps the main stream's chain, this one takes the weight gradients, the sort of
-// the ids and the loss value -- two fifths of the launches.  Jobs run in the order they were posted, so a side stream
-// sees its launches in program order as long as nobody else launches into it; the calling thread touches those streams
-// again only after wait_done() on the jobs concerned.  The thread spins for a short while before it sleeps (a wake-up
-// through the kernel costs more than the launch it would then perform).
-struct SideLauncher {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    std::deque<std::function<int()>> jobs;
-    std::atomic<uint64_t> posted{0}, done{0};
-    bool stop = false;
-    int rc = DLRM_OK;          // first failure since the last wait_done that reported one
-    std::string msg;
-    int device = 0;
-
-    void start(int dev) {
-        device = dev;
-        th = std::thread([this] { run(); });
-    }
-    void run() {
-        (void)hipSetDevice(device);
-        for (;;) {
-            std::function<int()> fn;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                if (jobs.empty() && !stop) {
-                    lk.unlock();
-                    const uint64_t seen = done.load(std::memory_order_relaxed);
-                    const auto t0 = std::chrono::steady_clock::now();
-                    while (posted.load(std::memory_order_acquire) == seen &&
-                           std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200))
-                        __builtin_ia32_pause();
-                    lk.lock();
-                    cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
-                }
-                if (jobs.empty()) return;      // stop
-                fn = std::move(jobs.front());
-                jobs.pop_front();
-            }
-            bool skip;
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                skip = rc != DLRM_OK;           // after a failure the rest of the step's jobs are dropped
-            }
-            const int r = skip ? (int)DLRM_OK : fn();
-            std::string why;
-            if (r) why = dlrm_last_error();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (r && rc == DLRM_OK) { rc = r; msg = why; }
-                done.fetch_add(1, std::memory_order_release);
-            }
-            cv_done.notify_all();
-        }
-    }
-    uint64_t post(std::function<int()> fn) {
-        uint64_t seq;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            jobs.push_back(std::move(fn));
-            seq = posted.fetch_add(1, std::memory_order_release) + 1;
-        }
-        cv_job.notify_one();
-        return seq;
-    }
-    // returns once the first `seq` jobs have run; reports (and forgets) a failure among the jobs run so far
-    int wait_done(uint64_t seq) {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (done.load(std::memory_order_acquire) < seq && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200))
-            __builtin_ia32_pause();
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) >= seq; });
-        if (rc == DLRM_OK) return DLRM_OK;
-        const int r = rc;
-        const std::string why = msg;
-        rc = DLRM_OK;
-        msg.clear();
-        lk.unlock();
-        return set_error(r, "%s", why.c_str());
-    }
-    int drain() { return wait_done(posted.load(std::memory_order_acquire)); }
-    void shutdown() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv_job.notify_one();
-        if (th.joinable()) th.join();
-    }
 };
 
 }  // namespace dlrm
@@ -197,13 +93,10 @@ struct dlrm_model {
     hipStream_t s_emb = nullptr, s_prep = nullptr, s_wgrad = nullptr, s_reduce = nullptr;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
-    SideLauncher *launcher = nullptr;     // small batches: the side streams' launches from a second host thread
-    uint64_t prep_job = 0;                // the job that launched this step's sort
-    std::vector<SlabReduce> pend_bot, pend_top;   // where the stacks' partial weight gradients wait for their reduction
     // optional timing of operator classes: event pairs around the launches, on the launch stream
     struct TimeRec { int cls; hipEvent_t e0, e1; };
     std::vector<TimeRec> trecs;
-    std::atomic<size_t> n_trecs{0};
+    size_t n_trecs = 0;
     uint32_t time_mask = 0;
     // captured steps (cfg.graph_steps): one instantiated graph per set of batch buffers
     struct Captured { const void *idx, *off; int64_t n; hipStream_t stream; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
@@ -232,38 +125,11 @@ static int wait_for(dlrm_model *m, hipStream_t a, hipStream_t b) {
     return DLRM_OK;
 }
 
-// Launches into a side stream (weight gradients, sort, loss value): through the launcher thread when the model has one
-// and `s` is one of its streams, else here and now.
-static bool launcher_owns(const dlrm_model *m, hipStream_t s) {
-    return m->launcher != nullptr && s != nullptr && (s == m->s_wgrad || s == m->s_prep);
-}
-template <typename F>
-static int side_do(dlrm_model *m, hipStream_t s, F &&fn, uint64_t *job = nullptr) {
-    if (!launcher_owns(m, s)) return fn();
-    const uint64_t seq = m->launcher->post(std::function<int()>(std::forward<F>(fn)));
-    if (job) *job = seq;
-    return DLRM_OK;
-}
-// side stream a waits for everything queued on stream b (one of the calling thread's) so far
-static int side_wait_for(dlrm_model *m, hipStream_t a, hipStream_t b) {
-    if (a == b) return DLRM_OK;
-    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
-    DLRM_HIP(hipEventRecord(e, b));
-    return side_do(m, a, [a, e]() -> int {
-        DLRM_HIP(hipStreamWaitEvent(a, e, 0));
-        return DLRM_OK;
-    });
-}
-// the calling thread is about to use the side streams itself (record an event there): every job has been launched
-static int side_drain(dlrm_model *m) { return m->launcher ? m->launcher->drain() : (int)DLRM_OK; }
-
 // runs `fn` (one operator call on stream s); when its class is being timed, between two events on s
 template <typename F>
 static int timed(dlrm_model *m, int cls, hipStream_t s, F &&fn) {
-    if (!(m->time_mask & (1u << cls)) || m->n_trecs.load() >= m->trecs.size()) return fn();
-    const size_t slot = m->n_trecs.fetch_add(1);      // (the launcher thread times its launches too)
-    if (slot >= m->trecs.size()) { m->n_trecs.store(m->trecs.size()); return fn(); }
-    dlrm_model::TimeRec &r = m->trecs[slot];
+    if (!(m->time_mask & (1u << cls)) || m->n_trecs >= m->trecs.size()) return fn();
+    dlrm_model::TimeRec &r = m->trecs[m->n_trecs++];
     r.cls = cls;
     DLRM_HIP(hipEventRecord(r.e0, s));
     const int rc = fn();
@@ -390,20 +256,16 @@ static int linear_wgrad(dlrm_model *m, const Layer &l, const float *dz, int64_t 
         d.d_dz_absmax = m->amax_valid[l.s_dz] ? m->amax + l.s_dz : nullptr;
         d.d_x_absmax = m->amax_valid[l.s_x] ? m->amax + l.s_x : nullptr;
     }
-    // (the descriptor is complete here, on the calling thread, which owns amax_valid; the launch may be the launcher thread's)
-    const Layer *lp = &l;
-    return side_do(m, s, [m, d, lp, pending, s]() -> int {
-        return timed(m, skinny_shape(lp->N, lp->K) ? DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY : DLRM_TIME_LINEAR_BACKWARD_WEIGHT, s,
-                     [&] {
-                         // DLRM_WGRAD_DEFER=0 (A/B aid): every layer adds its partial sums up by itself
-                         static const bool defer = [] { const char *e = getenv("DLRM_WGRAD_DEFER"); return !(e && e[0] == '0'); }();
-                         if (!defer) {
-                             pending->splits = 0;
-                             return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s);   // (one area for all: as before)
-                         }
-                         return linear_backward_weight_deferred(&d, static_cast<char *>(m->ws_dense) + lp->ws_off, lp->ws_bytes, pending, s);
-                     });
-    });
+    return timed(m, skinny_shape(l.N, l.K) ? DLRM_TIME_LINEAR_BACKWARD_WEIGHT_SKINNY : DLRM_TIME_LINEAR_BACKWARD_WEIGHT, s,
+                 [&] {
+                     // DLRM_WGRAD_DEFER=0 (A/B aid): every layer adds its partial sums up by itself
+                     static const bool defer = [] { const char *e = getenv("DLRM_WGRAD_DEFER"); return !(e && e[0] == '0'); }();
+                     if (!defer) {
+                         pending->splits = 0;
+                         return dlrm_linear_backward_weight(&d, m->ws_dense, m->ws_dense_bytes, s);   // (one area for all: as before)
+                     }
+                     return linear_backward_weight_deferred(&d, static_cast<char *>(m->ws_dense) + l.ws_off, l.ws_bytes, pending, s);
+                 });
 }
 
 // Backward of one MLP stack (MLPStack.backward): the weight gradient of every layer goes to the wgrad stream
@@ -413,8 +275,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
                           float *dx_first, int64_t dx_first_ld, hipStream_t s, bool last_dgrad_done = false) {
     const int n = (int)st.size();
     hipStream_t sw = m->s_wgrad ? m->s_wgrad : s;
-    std::vector<SlabReduce> &pending = &st == &m->bot ? m->pend_bot : m->pend_top;    // (outlives this call: the launcher thread fills it)
-    pending.assign((size_t)n, SlabReduce{});
+    std::vector<SlabReduce> pending((size_t)n);
     for (int i = n - 1; i >= 0; i--) {
         const float *dz = i == n - 1 ? dz_last : dz_bufs[i].p;
         const int64_t dz_ld = i == n - 1 ? dz_last_ld : dz_bufs[i].ld;
@@ -422,7 +283,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
         const int64_t xl = i == 0 ? x_in_ld : acts[i - 1].ld;
         if (big_layer(m, st[i]))                          // (a dz that no GEMM wrote: measured here, ahead of both readers)
             if (int rc = need_max(m, st[i].s_dz, dz, st[i].N, dz_ld, m->B, s)) return rc;
-        if (int rc = side_wait_for(m, sw, s)) return rc;      // dz of this layer is complete
+        if (int rc = wait_for(m, sw, s)) return rc;      // dz of this layer is complete
         if (int rc = linear_wgrad(m, st[i], dz, dz_ld, x, xl, sw, &pending[(size_t)i])) return rc;
         if (i == n - 1 && last_dgrad_done) continue;      // (dz_bufs[n - 2] came with the loss gradient)
         if (i > 0) {
@@ -435,10 +296,7 @@ static int stack_backward(dlrm_model *m, const std::vector<Layer> &st, const flo
     }
     // the partial sums of all layers of the stack, one launch (a reduction per layer is a string of 5-50 us launches
     // on the weight-gradient stream: 0.1 ms of a 0.9 ms step at a local batch of 8192)
-    SlabReduce *pend = pending.data();
-    return side_do(m, sw, [m, pend, n, sw]() -> int {
-        return timed(m, DLRM_TIME_LINEAR_BACKWARD_WEIGHT_REDUCE, sw, [&] { return reduce_slabs_many(pend, n, sw); });
-    });
+    return timed(m, DLRM_TIME_LINEAR_BACKWARD_WEIGHT_REDUCE, sw, [&] { return reduce_slabs_many(pending.data(), n, sw); });
 }
 
 static int emb_forward(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, hipStream_t s) {
@@ -511,11 +369,8 @@ static int sparse_update(dlrm_model *m, bool rw, const void *idx, const void *of
 static int emb_backward(dlrm_model *m, const void *idx, const void *off, int64_t n_idx, hipStream_t s) {
     const int D = m->D;
     const int64_t B = m->B;
-    if (m->cfg.presort && m->s_prep) {
-        if (m->launcher)       // the sort's launches have been handed over: the event below goes behind them
-            if (int rc = m->launcher->wait_done(m->prep_job)) return rc;
+    if (m->cfg.presort && m->s_prep)
         if (int rc = wait_for(m, s, m->s_prep)) return rc;
-    }
     if (!m->sharded) return sparse_update(m, false, idx, off, n_idx, m->dfeat + m->emb_col0, m->feat_ld, s);
     if (!m->views) {
         std::vector<dlrm_copy_item> items;
@@ -573,22 +428,20 @@ static int forward_pass(dlrm_model *m, const void *idx, const void *off, int64_t
     auto launch_prepare = [&]() -> int {
         if (!prep_todo) return DLRM_OK;
         prep_todo = false;
-        return side_do(m, prep, [m, prep, prep_from, idx, off, n_idx]() -> int {
-            if (prep_from) DLRM_HIP(hipStreamWaitEvent(prep, prep_from, 0));
-            if (m->Tl) {
-                dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
-                if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
-                                   [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse, m->ws_sparse_bytes, prep); }))
-                    return rc;
-            }
-            if (m->Trw && m->sharded) {
-                dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
-                if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
-                                   [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse_rw, m->ws_sparse_rw_bytes, prep); }))
-                    return rc;
-            }
-            return DLRM_OK;
-        }, &m->prep_job);
+        if (prep_from) DLRM_HIP(hipStreamWaitEvent(prep, prep_from, 0));
+        if (m->Tl) {
+            dlrm_embbag e = table_desc(m, false, idx, off, n_idx);
+            if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
+                               [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse, m->ws_sparse_bytes, prep); }))
+                return rc;
+        }
+        if (m->Trw && m->sharded) {
+            dlrm_embbag e = table_desc(m, true, idx, off, n_idx);
+            if (int rc = timed(m, DLRM_TIME_EMBBAG_BACKWARD_PREPARE, prep,
+                               [&] { return dlrm_embbag_backward_prepare(&e, m->ws_sparse_rw, m->ws_sparse_rw_bytes, prep); }))
+                return rc;
+        }
+        return DLRM_OK;
     };
     if (prep == main)      // (no stream of its own: program order is device order)
         if (int rc = launch_prepare()) return rc;
@@ -664,11 +517,6 @@ static void greedy_owner(const int64_t *rows, int T, int world, std::vector<int>
 
 extern "C" int dlrm_model_destroy(dlrm_model *m) {
     if (!m) return DLRM_OK;
-    if (m->launcher) {
-        m->launcher->shutdown();
-        delete m->launcher;
-        m->launcher = nullptr;
-    }
     (void)hipDeviceSynchronize();
     for (void *p : m->allocs) (void)hipFree(p);
     for (auto &g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -762,20 +610,7 @@ extern "C" int dlrm_model_create(const dlrm_model_config *c, dlrm_model **out) {
         if (hipStreamCreateWithFlags(&m->s_wgrad, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
     if (sharded && c->comm_dense != nullptr)      // the dense gradients' all-reduce beside the rest of the backward pass
         if (hipStreamCreateWithFlags(&m->s_reduce, hipStreamNonBlocking) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "stream"));
-    // a launcher thread where the host's share of a step is the step's length (local batches below 8192: Criteo-Kaggle's
-    // 2048 +4.4 %; at 8192 the device is the slower side and nothing changes; a captured step is launched by one call
-    // anyway); DLRM_LAUNCH_THREAD=0 / 1 switches it off / on regardless of the batch
-    {
-        const char *e = getenv("DLRM_LAUNCH_THREAD");
-        const bool want = e ? e[0] != '0' : c->local_batch < 8192;
-        if (want && !c->graph_steps && (m->s_wgrad || m->s_prep)) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "hipGetDevice"));
-            m->launcher = new SideLauncher();
-            m->launcher->start(dev);
-        }
-    }
-    m->events.resize(256);
+    m->events.resize(64);
     for (auto &e : m->events)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(set_error(DLRM_ERR_HIP, "event"));
 
@@ -1114,9 +949,7 @@ extern "C" int dlrm_model_train_step(dlrm_model *m, const void *d_indices, const
     // (a step that brackets operators with timing events, and the exchanges of a sharded step, are launched directly)
     if (m->cfg.graph_steps && !m->sharded && m->time_mask == 0 && main != nullptr)
         return graphed_step(m, d_indices, d_offsets, n_indices, main);
-    const int rc = train_step_impl(m, d_indices, d_offsets, n_indices, main);
-    const int rc2 = side_drain(m);       // (a step that failed half way leaves no job behind either)
-    return rc ? rc : rc2;
+    return train_step_impl(m, d_indices, d_offsets, n_indices, main);
 }
 
 static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_offsets, int64_t n_indices, hipStream_t main) {
@@ -1139,17 +972,15 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
             }))
             return rc;
     }
-    if (int rc = side_wait_for(m, side, main)) return rc;    // the predictions are there
+    if (int rc = wait_for(m, side, main)) return rc;    // the predictions are there
     for (int half = m->fuse_last ? 1 : 0; half < 2; half++) {
         float *lo = half ? m->loss : nullptr, *gr = half ? nullptr : m->dpred;
         hipStream_t s = half ? side : main;
-        const bool bce = c.loss == DLRM_LOSS_BCE;
-        const int relu = c.final_relu;
-        if (int rc = side_do(m, s, [m, lo, gr, s, bce, relu]() -> int {
-                if (bce) return dlrm_loss_bce_logits(m->pred, m->labels, m->B, m->Bg, lo, gr, s);
-                return dlrm_loss_mse(m->pred, m->labels, m->B, m->Bg, lo, gr, relu, s);
-            }))
-            return rc;
+        if (c.loss == DLRM_LOSS_BCE) {
+            if (int rc = dlrm_loss_bce_logits(m->pred, m->labels, m->B, m->Bg, lo, gr, s)) return rc;
+        } else {
+            if (int rc = dlrm_loss_mse(m->pred, m->labels, m->B, m->Bg, lo, gr, c.final_relu, s)) return rc;
+        }
     }
     // top MLP backward, interaction backward
     if (m->dot) {
@@ -1181,7 +1012,6 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
     const bool early_reduce = m->sharded && c.comm_dense != nullptr && m->s_reduce != nullptr;
     const int64_t top_off = m->topl.front().w_off;
     if (early_reduce) {
-        if (int rc = side_drain(m)) return rc;
         if (int rc = wait_for(m, m->s_reduce, m->s_wgrad ? m->s_wgrad : main)) return rc;    // the top stack's weight gradients are there
         if (int rc = timed(m, DLRM_TIME_COMM_ALL_REDUCE, m->s_reduce, [&] {
                 return dlrm_comm_all_reduce_sum(c.comm_dense, m->grads + top_off, m->n_params - top_off, m->s_reduce);
@@ -1200,7 +1030,6 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
     if (int rc = stack_backward(m, m->bot, m->x_dense, m->x_ld, m->bot_acts, m->dfeat, m->feat_ld, m->bot_dz, nullptr, 0, main)) return rc;
     if (emb_last)
         if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, main)) return rc;
-    if (int rc = side_drain(m)) return rc;     // (the launcher thread has handed everything over: events on its streams see it all)
     if (m->s_wgrad)
         if (int rc = wait_for(m, main, m->s_wgrad)) return rc;   // every dense gradient is there
     if (early_reduce) {
