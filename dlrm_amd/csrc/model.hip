@@ -1022,7 +1022,8 @@ static int train_step_impl(dlrm_model *m, const void *d_indices, const void *d_o
     // Without a stream of its own the sparse update goes behind the bottom MLP's data gradients: ahead of them it would
     // only delay the events the weight-gradient stream waits for (small batches: that stream's chain is the step's tail).
     static const bool emb_last_ok = [] { const char *e = getenv("DLRM_EMB_LAST"); return !(e && e[0] == '0'); }();
-    const bool emb_last = emb == main && m->s_wgrad != nullptr && emb_last_ok;
+    // (a captured step keeps the old place: replayed from a graph this order measured slower, 0.40 against 0.36 ms)
+    const bool emb_last = emb == main && m->s_wgrad != nullptr && emb_last_ok && !m->cfg.graph_steps;
     if (!emb_last) {
         if (int rc = wait_for(m, emb, main)) return rc;     // dfeat is complete
         if (int rc = emb_backward(m, d_indices, d_offsets, n_indices, emb)) return rc;
