@@ -189,7 +189,7 @@ KERNEL_OF = {
     "linear_backward_weight_skinny": "skinny_k_bwd_weight_kernel / gemv_bwd_weight_kernel + reduce_slabs",
     "comm_forward_exchange": "RCCL all-to-all of pooled vectors (reduce-scatter for row-wise tables), peers' arrival included",
     "comm_backward_exchange": "RCCL all-to-all of their gradients (all-gather for row-wise tables)",
-    "comm_all_reduce": "RCCL all-reduce of the dense gradients (second communicator: beside the backward pass)",
+    "comm_all_reduce": "RCCL all-reduce of the dense gradients (with --two-comms: on a second communicator, beside the backward pass)",
 }
 
 
