@@ -344,6 +344,35 @@ def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtyp
     assert int(flag.item()) == 2
 
 
+def test_interact_dot_gather_rejects_what_it_cannot_read():
+    """The gathering interaction kernels take float32 rows of a power-of-two width, one id per bag for every table and a
+    gradient / output row long enough for the pairs: anything else is an error with a message, not a launch."""
+    from dlrm_amd import _capi, ops
+    B, T = 64, 3
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tro = torch.tensor([0, 10, 20, 30], dtype=torch.int64, device="cuda")
+    indices = torch.zeros(T * B, dtype=torch.int32, device="cuda")
+    offsets = torch.arange(T * B + 1, dtype=torch.int32, device="cuda")
+
+    def both(weight, D, idx=indices, out_ld=None, match=""):
+        x0 = torch.zeros((B, D), dtype=torch.float32, device="cuda")
+        n_out = D + (T + 1) * T // 2
+        dout = torch.zeros((B, n_out if out_ld is None else out_ld), dtype=torch.float32, device="cuda")
+        with pytest.raises(_capi.DlrmError, match=match):
+            ops.interact_dot_forward_gather(weight, idx, offsets, B, T, tro, x0, out_ld=out_ld, error_flag=flag,
+                                            include_last_offset=True)
+        with pytest.raises(_capi.DlrmError, match=match):
+            ops.interact_dot_backward_gather(weight, idx, offsets, B, T, tro, x0, dout, error_flag=flag,
+                                             include_last_offset=True)
+
+    both(torch.zeros((30, 16), dtype=torch.bfloat16, device="cuda"), 16, match="float32 rows")
+    both(torch.zeros((30, 24), dtype=torch.float32, device="cuda"), 24, match="power-of-two")
+    both(torch.zeros((30, 16), dtype=torch.float32, device="cuda"), 16, idx=indices[:T * B - 1], match="one id per bag")
+    both(torch.zeros((30, 16), dtype=torch.float32, device="cuda"), 16, out_ld=16, match="too small")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+
+
 @pytest.mark.parametrize("n", [1, 60, 2048, 65536])
 def test_losses(oracle, n):
     from dlrm_amd import ops
