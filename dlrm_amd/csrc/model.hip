@@ -873,10 +873,10 @@ extern "C" int dlrm_model_load_batch(dlrm_model *m, const float *d_dense, int64_
                                      dlrm_stream_t stream) {
     DLRM_REQUIRE(m != nullptr && d_dense != nullptr && d_labels != nullptr, "NULL argument");
     DLRM_REQUIRE(dense_ld >= m->cfg.dense_in, "dense_ld too small");
-    hipStream_t s = as_stream(stream);
-    if (int rc = dlrm_copy_2d(m->x_dense, m->x_ld, d_dense, dense_ld, m->B, m->cfg.dense_in, s)) return rc;
-    DLRM_HIP(hipMemcpyAsync(m->labels, d_labels, sizeof(float) * m->B, hipMemcpyDeviceToDevice, s));
-    return DLRM_OK;
+    // both copies in one launch (the labels as a [B, 1] block): a small step is a chain of dependent launches
+    const dlrm_copy_item items[2] = {{m->x_dense, m->x_ld, d_dense, dense_ld, m->B, m->cfg.dense_in},
+                                     {m->labels, 1, d_labels, 1, m->B, 1}};
+    return dlrm_copy_2d_many(items, 2, stream);
 }
 
 static int ensure_sparse_ws(dlrm_model *m, const void *idx, const void *off, int64_t n_idx) {
