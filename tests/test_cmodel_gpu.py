@@ -284,6 +284,50 @@ def test_c_hosted_graphed_steps_equal_direct_launches(one_id, gemm):
             assert torch.equal(a, b), "%s: %s differ from the direct launches" % (name, what)
 
 
+@pytest.mark.parametrize("name", ["kaggle_like", "adagrad_bf16rows_off"])
+def test_c_hosted_step_without_a_single_id(oracle, name):
+    """A batch whose bags are all empty (n_indices = 0): the pooled vectors are zero, no row changes, the dense side
+    steps as the oracle's does.  Then a batch with ids again: the step goes on as usual."""
+    from dlrm_amd.cmodel import CModel
+    cfg = small_cfgs()[name]
+    B, T = 37, cfg.num_tables
+    m = CModel(cfg, B, seed=3, idx_dtype=torch.int64)
+    m.init_dense(7)
+    Ws, bs = m.get_dense()
+    got = tables_of(m)
+    tables = [got[t][0] for t in range(T)]
+    state = None if m.opt_state is None else np.zeros(sum(cfg.table_rows), np.float32)
+    n_bottom = len(cfg.bottom)
+    rng = np.random.default_rng(5)
+    for step in range(2):
+        dense, idx, off, labels = make_batch(rng, cfg, B, False)
+        if step == 0:
+            idx = np.zeros(0, np.int64)
+            off = np.zeros(T * B + 1, np.int64)
+        li, lo = local_batch_ids(m, cfg, idx, off, B)
+        m.load_batch(torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        d_idx = torch.from_numpy(li).cuda() if li.size else torch.zeros(1, dtype=torch.int64, device="cuda")[:0]
+        loss = m.train_step(d_idx, torch.from_numpy(lo).cuda())
+        torch.cuda.synchronize()
+        assert int(m.err_flag.item()) == 0
+        before = [t.copy() for t in tables]
+        loss_ref, pred_ref = oracle_train_step(oracle, cfg, tables, Ws, bs, dense, idx, off, labels, n_bottom, cfg.lr,
+                                               feature_order=m.feature_order, emb_opt_state=state)
+        if step == 0:
+            for a, b in zip(before, tables):
+                assert np.array_equal(a, b)
+        assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+        assert rel_err(m.pred.cpu().numpy().reshape(-1), pred_ref) <= 1e-5
+        for t, (a, _) in tables_of(m).items():
+            if step == 0:
+                assert np.array_equal(a, before[t]), t
+            assert rel_err(a, tables[t]) <= 1e-5, t
+        gW, gb = m.get_dense()
+        for a, r in zip(gW + gb, Ws + bs):
+            assert rel_err(a, r) <= 1e-5
+    m.close()
+
+
 _FUSE_CASE = """
 import sys
 sys.path.insert(0, %(root)r)
