@@ -271,7 +271,8 @@ def test_interact_dot(oracle, B, F, D):
 
 @pytest.mark.parametrize("B,T,D,idx_dtype", [(300, 26, 128, torch.int32), (2048, 26, 16, torch.int32), (77, 3, 64, torch.int64),
                                              (4100, 7, 32, torch.int32), (65, 31, 8, torch.int32),
-                                             (131105, 2, 8, torch.int32)])    # more chunks of 32 samples than workgroups
+                                             (131105, 2, 8, torch.int32),     # more chunks of 32 samples than workgroups
+                                             (65536, 26, 128, torch.int32)])  # the MLPerf shape at its full batch (kernel against kernel)
 def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtype):
     """One id per bag: the interaction forward that reads the rows straight from the tables gives, bit for bit, what
     EmbeddingBag forward + the interaction on its output give (same arithmetic on the same values), and its optional
@@ -308,8 +309,9 @@ def test_interact_dot_gather_equals_pool_then_interact(oracle, B, T, D, idx_dtyp
     assert int(flag.item()) == 0
     assert torch.equal(out, ref_out)
     assert torch.equal(out2, ref_out) and torch.equal(x2, x)
-    z_ref = oracle.interact_dot_forward(x.cpu().numpy())
-    assert rel_err(out[:, :n_out].cpu().numpy(), z_ref) <= 1e-5
+    if B * F * D <= 1 << 24:       # (the full-batch case is held to the other kernels only: bit for bit, above and below)
+        z_ref = oracle.interact_dot_forward(x.cpu().numpy())
+        assert rel_err(out[:, :n_out].cpu().numpy(), z_ref) <= 1e-5
     # the backward pass that gathers the rows again (no copy of the block) writes what the one given the block writes
     dout = torch.from_numpy(rng.standard_normal((B, out_ld)).astype(np.float32)).cuda()
     for mask in (False, True):
