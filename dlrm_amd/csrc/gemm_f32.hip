@@ -1441,40 +1441,52 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitJobs jobs) {
 // such problems with the same number of slabs (a weight gradient and its bias gradient): workgroups
 // [0, blocks_a) take the first, the rest the second.
 // (struct SlabSum: common.h)
-__device__ inline void reduce_slabs_body(const SlabSum &p, int splits, unsigned bid, unsigned nblk) {
-    __shared__ float part[4][64];
+// W = 4: every thread takes four consecutive outputs with 16-byte loads and one 16-byte store (rows, slabs and the
+// output start on 16-byte boundaries); the sums and their order per output are those of W = 1.
+__device__ inline bool slab_sum_vec(const SlabSum &p) {
+    return p.cols % 4 == 0 && p.stride % 4 == 0 && p.ld_out % 4 == 0 && reinterpret_cast<uintptr_t>(p.slabs) % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(p.out) % 16 == 0;
+}
+template <int W>
+__device__ inline void reduce_slabs_w(const SlabSum &p, int splits, unsigned bid, unsigned nblk, float (*part)[64 * 4]) {
+    typedef float vecw __attribute__((ext_vector_type(W)));
     const float *__restrict__ slabs = p.slabs;
     const int64_t n = (int64_t)p.rows * p.cols;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int64_t i0 = (int64_t)bid * 64; i0 < n; i0 += (int64_t)nblk * 64) {
-        const int64_t i = i0 + e;
-        float a = 0.f;
+    for (int64_t i0 = (int64_t)bid * 64 * W; i0 < n; i0 += (int64_t)nblk * 64 * W) {
+        const int64_t i = i0 + (int64_t)e * W;
+        vecw a = 0.f;
         if (i < n) {
             int s = q;
             for (; s + 28 < splits; s += 32) {
-                float v[8];
+                vecw v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(s + 4 * u) * p.stride + i];
+                for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const vecw *>(slabs + (int64_t)(s + 4 * u) * p.stride + i);
 #pragma unroll
                 for (int u = 0; u < 8; u++) a += v[u];
             }
-            for (; s < splits; s += 4) a += slabs[(int64_t)s * p.stride + i];
+            for (; s < splits; s += 4) a += *reinterpret_cast<const vecw *>(slabs + (int64_t)s * p.stride + i);
         }
-        part[q][e] = a;
+        *reinterpret_cast<vecw *>(&part[q][e * W]) = a;
         __syncthreads();
         if (q == 0 && i < n) {
-            const float t = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+            const vecw t = (*reinterpret_cast<const vecw *>(&part[0][e * W]) + *reinterpret_cast<const vecw *>(&part[1][e * W])) +
+                           (*reinterpret_cast<const vecw *>(&part[2][e * W]) + *reinterpret_cast<const vecw *>(&part[3][e * W]));
             const int r = (int)(i / p.cols), c = (int)(i - (int64_t)r * p.cols);
-            p.out[(int64_t)r * p.ld_out + c] = t;
+            *reinterpret_cast<vecw *>(p.out + (int64_t)r * p.ld_out + c) = t;
         }
         __syncthreads();
     }
 }
+__device__ inline void reduce_slabs_body(const SlabSum &p, int splits, unsigned bid, unsigned nblk) {
+    __shared__ __attribute__((aligned(16))) float part[4][64 * 4];
+    if (slab_sum_vec(p)) reduce_slabs_w<4>(p, splits, bid, nblk, part);
+    else reduce_slabs_w<1>(p, splits, bid, nblk, part);
+}
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(SlabSum pa, SlabSum pb, int splits, unsigned blocks_a) {
-    const bool second = blockIdx.x >= blocks_a;
-    reduce_slabs_body(second ? pb : pa, splits, second ? blockIdx.x - blocks_a : blockIdx.x,
-                      second ? gridDim.x - blocks_a : blocks_a);
+    if (blockIdx.x >= blocks_a) reduce_slabs_body(pb, splits, blockIdx.x - blocks_a, gridDim.x - blocks_a);
+    else reduce_slabs_body(pa, splits, blockIdx.x, blocks_a);
 }
 
 // the same for up to kReduceJobs problems with their own numbers of slabs: workgroups [first[j], first[j+1]) take job j
@@ -1491,7 +1503,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_many_kernel(ReduceJobs jobs)
     reduce_slabs_body(jobs.p[j], jobs.splits[j], blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j]);
 }
 
-static unsigned reduce_blocks(int64_t n) { return (unsigned)(ceil_div(n, 64) < 4096 ? ceil_div(n, 64) : 4096); }
+static bool slab_sum_vec_host(const SlabSum &p) {
+    return p.cols % 4 == 0 && p.stride % 4 == 0 && p.ld_out % 4 == 0 && reinterpret_cast<uintptr_t>(p.slabs) % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(p.out) % 16 == 0;
+}
+static unsigned reduce_blocks(const SlabSum &p) {
+    const int64_t per = slab_sum_vec_host(p) ? 256 : 64;
+    const int64_t n = ceil_div((int64_t)p.rows * p.cols, per);
+    return (unsigned)(n < 4096 ? (n < 1 ? 1 : n) : 4096);
+}
 
 int reduce_slabs_many(const SlabReduce *items, int n, hipStream_t s) {
     DLRM_REQUIRE(n >= 0 && (items != nullptr || n == 0), "bad arguments");
@@ -1509,7 +1529,7 @@ int reduce_slabs_many(const SlabReduce *items, int n, hipStream_t s) {
         if (jobs.n == 0) jobs.first[0] = 0;
         jobs.p[jobs.n] = p;
         jobs.splits[jobs.n] = splits;
-        jobs.first[jobs.n + 1] = jobs.first[jobs.n] + reduce_blocks((int64_t)p.rows * p.cols);
+        jobs.first[jobs.n + 1] = jobs.first[jobs.n] + reduce_blocks(p);
         jobs.n++;
         return DLRM_OK;
     };
@@ -1526,11 +1546,10 @@ int reduce_slabs_many(const SlabReduce *items, int n, hipStream_t s) {
 // (pending: the reduction is not launched but written down for reduce_slabs_many)
 static int launch_reduce(const float *slabs, int64_t stride, int N, int K, float *dw, int64_t dw_ld, const float *db_slabs,
                          float *db, int splits, hipStream_t s, SlabReduce *pending = nullptr) {
-    const int64_t n = (int64_t)N * K;
-    const unsigned blocks_a = reduce_blocks(n);
-    const unsigned blocks_b = db ? (unsigned)ceil_div(N, 64) : 0u;
     SlabSum a{slabs, stride, N, K, dw, dw_ld};
     SlabSum b{db_slabs, (int64_t)N, 1, N, db, (int64_t)N};
+    const unsigned blocks_a = reduce_blocks(a);
+    const unsigned blocks_b = db ? reduce_blocks(b) : 0u;
     if (pending) {
         pending->w = a; pending->b = b; pending->splits = splits; pending->has_b = db != nullptr;
         return DLRM_OK;
